@@ -1,0 +1,120 @@
+/*
+ * te_config.c — reference constants per task (plain C, no HIP): te_config_default and the
+ * algorithmic-bytes formula.  Interface data only; shared by libthreatengage.so and by the
+ * test oracle so both are configured from one table.
+ *
+ * Citations are file:line under the reference's src/ tree.
+ */
+#include <math.h>
+#include <string.h>
+
+#include "../../include/threatengage.h"
+
+#if defined(__GNUC__)
+#define TE_API __attribute__((visibility("default")))
+#else
+#define TE_API
+#endif
+
+/* Task.calculate_rounds (level4/components/tasks_management/tasks/exp03_vFinal_task.py:198-226):
+ * ceil of the positive root of n^2 + n - 2 * defenders * munition = 0 */
+static int calculate_rounds(int defenders, int munition) {
+  double total = (double)defenders * (double)munition;
+  double root = (-1.0 + sqrt(1.0 + 8.0 * total)) / 2.0;
+  return (int)ceil(root);
+}
+
+/* PyFlyt 0.11.1 "cf2x" (models/vehicles/cf2x/cf2x.yaml + cf2x.urdf), recorded in SURVEY.md
+ * Appendix B from the public sources.  UNVERIFIED here: pyflyt is absent from this container. */
+static void cf2x_defaults(te_quad_params* q) {
+  q->mass = 0.027f;
+  q->inertia[0] = 1.4e-5f; q->inertia[1] = 1.4e-5f; q->inertia[2] = 2.17e-5f;
+  q->arm = 0.028f;
+  q->total_thrust = 0.5886f;
+  q->thrust_coef = 3.16e-10f;
+  q->torque_coef = 7.94e-12f;
+  q->motor_tau = 0.01f;
+  q->noise_ratio = 0.02f;
+  q->drag_coef_xyz = 1.0f; q->drag_area_xyz = 0.01f; q->drag_coef_pqr = 1.0e-4f;
+  q->air_density = 1.225f;
+  q->gravity = 9.81f; /* level4_simulation.py:69-70 */
+  q->ang_vel_kp[0] = 8.0e-3f; q->ang_vel_kp[1] = 8.0e-3f; q->ang_vel_kp[2] = 1.0e-2f;
+  q->ang_vel_ki[0] = 2.5e-7f; q->ang_vel_ki[1] = 2.5e-7f; q->ang_vel_ki[2] = 1.3e-4f;
+  q->ang_vel_kd[0] = 1.0e-4f; q->ang_vel_kd[1] = 1.0e-4f; q->ang_vel_kd[2] = 0.0f;
+  q->ang_vel_lim[0] = 1.0f; q->ang_vel_lim[1] = 1.0f; q->ang_vel_lim[2] = 1.0f;
+  for (int i = 0; i < 3; ++i) { q->ang_pos_kp[i] = 2.0f; q->ang_pos_lim[i] = 3.0f; }
+  for (int i = 0; i < 2; ++i) {
+    q->lin_vel_kp[i] = 0.8f; q->lin_vel_ki[i] = 0.3f; q->lin_vel_kd[i] = 0.5f; q->lin_vel_lim[i] = 0.4f;
+    q->lin_pos_kp[i] = 1.0f; q->lin_pos_lim[i] = 2.0f;
+  }
+  q->z_pos_kp = 1.0f; q->z_pos_lim = 1.0f;
+  q->z_vel_kp = 0.15f; q->z_vel_ki = 1.0f; q->z_vel_kd = 0.015f; q->z_vel_lim = 1.0f;
+  q->pwm_floor = 0.05f;
+}
+
+TE_API int te_config_default(te_config* c, int32_t task) {
+  if (!c) return 1;
+  memset(c, 0, sizeof *c);
+  c->struct_size = (uint32_t)sizeof *c;
+  c->task = task;
+  c->n_envs = 1;
+  c->seed = 0;
+  c->max_speed = (float)(10.0 * 1000.0 / 3600.0); /* quadcopter.py:590-600 */
+  c->substeps = 16;            /* int(120/15) sim steps x 240//120 physics updates */
+  c->physics_dt = 1.0f / 240.0f;
+  c->control_dt = 1.0f / 120.0f;
+  c->observe_lag = 1;
+  c->shoot_range = 1.0f; c->explosion_range = 0.2f; c->origin_range = 0.2f; c->hit_prob = 0.9f;
+  c->cooldown_steps = 60;      /* gun.py:13-25 */
+  c->step_increment = 100;
+  c->born_radius = 6.0f; c->born_min_z = 4.0f;
+  c->invader_speed = 0.4f; c->ally_speed = 0.6f;
+  c->building_position[0] = 0.0f; c->building_position[1] = 0.0f; c->building_position[2] = 0.1f;
+  c->motor_noise = 1;
+  c->auto_reset = 1;
+  c->catch_distance = 0.4f;
+  cf2x_defaults(&c->quad);
+  switch (task) {
+    case TE_TASK_STAGE01: /* level2/pyflyt_level2_environment_modified_v2.py:27-73 */
+      c->n_pursuers = 2; c->n_invaders = 1;
+      c->dome_radius = 10.0f; c->lidar_radius = 20.0f; /* level2/components/quadcopter_manager.py:44 */
+      c->munition = 0; c->max_step = 300; c->n_rounds = 0;
+      c->pursuer_spawn_radius = 1.0f; c->ally_policy = TE_ALLY_NONE; c->approach_bonus_gain = 10.0f;
+      break;
+    case TE_TASK_STAGE02: /* level3/components/stages.py:65-83,118 ; env default dome 8 (pyflyt_level3_environment_v2.py:32) */
+      c->n_pursuers = 2; c->n_invaders = 5;
+      c->dome_radius = 8.0f; c->lidar_radius = 16.0f;
+      c->munition = 4; c->max_step = 600; c->n_rounds = 0;
+      c->pursuer_spawn_radius = 1.0f; c->ally_policy = TE_ALLY_NONE; c->approach_bonus_gain = 10.0f;
+      c->invader_speed = 0.5f; /* hover command magnitude (level3/components/quadcopter_manager.py:191) */
+      break;
+    case TE_TASK_EXP02: /* exp02_vFinal_task.py:87-111 */
+      c->n_pursuers = 1; c->munition = 20;
+      c->n_rounds = calculate_rounds(1, 20); c->n_invaders = c->n_rounds;
+      c->dome_radius = 20.0f; c->lidar_radius = 40.0f;
+      c->max_step = 300; c->pursuer_spawn_radius = 2.0f; c->ally_policy = TE_ALLY_NONE; c->approach_bonus_gain = 1.0f;
+      break;
+    case TE_TASK_EXP03: /* exp03_vFinal_task.py:88-112 */
+    case TE_TASK_EXP04: /* exp04_vFinal_task.py (ally frozen, bonus x10) */
+      c->n_pursuers = 2; c->munition = 20;
+      c->n_rounds = calculate_rounds(2, 20); c->n_invaders = c->n_rounds;
+      c->dome_radius = 20.0f; c->lidar_radius = 40.0f;
+      c->max_step = 300; c->pursuer_spawn_radius = 2.0f;
+      c->ally_policy = task == TE_TASK_EXP03 ? TE_ALLY_BT : TE_ALLY_FROZEN;
+      c->approach_bonus_gain = task == TE_TASK_EXP03 ? 1.0f : 10.0f;
+      break;
+    default:
+      return 2;
+  }
+  return 0;
+}
+
+/* B(P,I,C) = (P+I)*2*176 + 2*40 + 16 + (C*338*4 + 15*4 + 4*4 + 4 + 4) */
+TE_API int te_algorithmic_bytes_per_env_step(const te_config* c, size_t* out) {
+  if (!c || !out) return 1;
+  size_t D = (size_t)(c->n_pursuers + c->n_invaders);
+  *out = D * 2 * 176 + 2 * 40 + 16 + ((size_t)TE_LIDAR_CHANNELS * TE_LIDAR_CELLS * 4 + 15 * 4 + 4 * 4 + 4 + 4);
+  return 0;
+}
+
+TE_API int te_abi_version(void) { return TE_ABI_VERSION; }

@@ -1,0 +1,238 @@
+/*
+ * threatengage.h — C ABI of the batched threat-engagement drone environment
+ * (MI355X / gfx950 HIP implementation: dronechase_amd/libthreatengage.so).
+ *
+ * The reference (DaviGuanabara/dronechase) has no FFI: every environment is a
+ * Python gymnasium.Env driven one-process-per-env through SB3's SubprocVecEnv
+ * (src/core/rl_framework/utils/pipeline.py:31-61).  This header CREATES the
+ * seam: one `te_env` replaces N reference environments
+ * (src/threatengage/environments/level4/exp03_vFinal_environment.py:42-171 and
+ * siblings) and each entry point names the reference interface it stands for.
+ *
+ * Conventions
+ *   - plain C, no torch/HIP types in signatures; every I/O pointer is a DEVICE
+ *     pointer (hipMalloc'ed or a PyTorch-ROCm tensor's data_ptr()) unless the
+ *     name ends in `_host`.
+ *   - all functions return 0 on success, non-zero on failure; the message is
+ *     available from te_last_error() (thread-local, never NULL).
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
+ *     null stream) and is asynchronous; the caller synchronises.
+ *   - a te_env is not thread-safe; distinct te_envs (e.g. one per GPU) are
+ *     independent (mirrors the thread-local singletons of the reference,
+ *     level4/components/entities_management/entities_manager.py:24-30).
+ */
+#ifndef THREATENGAGE_H
+#define THREATENGAGE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TE_ABI_VERSION 1
+
+/* ---- tasks (reference env class each one mirrors) ----------------------- */
+enum {
+  TE_TASK_STAGE01 = 1, /* level2/pyflyt_level2_environment_modified_v2.py (apps stage01) */
+  TE_TASK_STAGE02 = 2, /* level3/pyflyt_level3_environment_v2.py + components/stages.py (apps stage02) */
+  TE_TASK_EXP02 = 3,   /* level4/exp02_vFinal_environment.py + tasks/exp02_vFinal_task.py */
+  TE_TASK_EXP03 = 4,   /* level4/exp03_vFinal_environment.py + tasks/exp03_vFinal_task.py (apps stage03) */
+  TE_TASK_EXP04 = 5    /* level4/exp04_vFinal_environment.py (ally frozen, x10 approach bonus) */
+};
+
+/* ally (pursuer slots >= 1) policy */
+enum { TE_ALLY_NONE = 0, TE_ALLY_BT = 1, TE_ALLY_FROZEN = 2 };
+
+/* kamikaze FSM states (core/entities/navigators/loitering_munition_navigator_air_combat_only.py:138-246) */
+enum { TE_NAV_WAIT = 0, TE_NAV_COLLIDE_WINGMAN = 1, TE_NAV_COLLIDE_BUILDING = 2 };
+
+/* entity types; LIDAR flag = type / 5 (core/entities/entity_type.py:4-14, lidar_math.py:305) */
+enum { TE_TYPE_LOITERINGMUNITION = 1, TE_TYPE_QUADCOPTER = 2, TE_TYPE_LOYALWINGMAN = 3,
+       TE_TYPE_PROTECTED_BUILDING = 4, TE_TYPE_GROUND = 5 };
+
+/* ---- LIDAR grid (core/dataclasses/angle_grid.py:28-37, resolution 16) --- */
+#define TE_LIDAR_NTHETA 13
+#define TE_LIDAR_NPHI 26
+#define TE_LIDAR_CELLS (TE_LIDAR_NTHETA * TE_LIDAR_NPHI) /* 338 */
+#define TE_LIDAR_CHANNELS 3                              /* distance, flag, time (core/enums/channel_index.py:7-9) */
+#define TE_OBS_LIDAR_WORDS (TE_LIDAR_CHANNELS * TE_LIDAR_CELLS) /* 1014 */
+#define TE_OBS_INERTIAL_WORDS 15 /* pos3 vel3 att3 rate3 gun3 (exp03_vFinal_environment.py:200-228) */
+#define TE_OBS_ACTION_WORDS 4
+#define TE_INFO_WORDS 4 /* agent_kills, allies_kills, deads, current_wave (exp03_vFinal_task.py:571-578) */
+
+/* ---- quadrotor model: PyFlyt 0.11.1 QuadX "cf2x" + Bullet free body ------
+ * The sources of these numbers (pyflyt 0.11.1, pybullet 3.2.7; poetry.lock:1412-1440)
+ * are NOT in the reference tree; te_config_default() fills the table recorded in
+ * SURVEY.md Appendix B (UNVERIFIED) so it can be corrected in one place. */
+typedef struct te_quad_params {
+  float mass;          /* kg */
+  float inertia[3];    /* diag(Ixx, Iyy, Izz) kg m^2 */
+  float arm;           /* |x| = |y| of each propeller, m */
+  float total_thrust;  /* N at throttle 1 on all four motors */
+  float thrust_coef;   /* N / rpm^2 */
+  float torque_coef;   /* N m / rpm^2 */
+  float motor_tau;     /* s, first-order lag */
+  float noise_ratio;   /* multiplicative Gaussian throttle noise */
+  float drag_coef_xyz, drag_area_xyz, drag_coef_pqr;
+  float air_density;
+  float gravity;       /* m/s^2, applied along -z (level4_simulation.py:69-70) */
+  float ang_vel_kp[3], ang_vel_ki[3], ang_vel_kd[3], ang_vel_lim[3];
+  float ang_pos_kp[3], ang_pos_lim[3];   /* ki = kd = 0 in cf2x: loop is memory-less */
+  float lin_vel_kp[2], lin_vel_ki[2], lin_vel_kd[2], lin_vel_lim[2];
+  float lin_pos_kp[2], lin_pos_lim[2];   /* mode 7 only; ki = kd = 0 */
+  float z_pos_kp, z_pos_lim;             /* mode 7 only; ki = kd = 0 */
+  float z_vel_kp, z_vel_ki, z_vel_kd, z_vel_lim;
+  float pwm_floor;     /* 0.05: minimum pwm after saturation handling */
+} te_quad_params;
+
+/* ---- configuration ----------------------------- */
+typedef struct te_config {
+  uint32_t struct_size;   /* = sizeof(te_config); checked by te_create */
+  int32_t task;           /* TE_TASK_* */
+  int32_t n_envs;         /* environments owned by this te_env (this GPU's shard) */
+  int32_t n_pursuers;     /* P; slot 0 is the RL agent */
+  int32_t n_invaders;     /* I */
+  int64_t env_index_base; /* global index of local env 0: RNG is keyed on the GLOBAL env index, so
+                             results do not depend on how envs are sharded over GPUs */
+  uint64_t seed;
+
+  float dome_radius;      /* 20 (level4), 10 (stage01), 8 (stage02) */
+  float lidar_radius;     /* 2 * dome_radius */
+  float max_speed;        /* 10 km/h = 2.7778 m/s: observation normaliser only (quadcopter.py:590-600) */
+
+  int32_t substeps;       /* physics sub-steps per env.step: 8 sim steps x 2 (level4_simulation.py:84-98) = 16 */
+  float physics_dt;       /* 1/240 */
+  float control_dt;       /* 1/120: PID period, although update_control runs every sub-step (reference quirk) */
+  int32_t observe_lag;    /* 1: IMU is read before the last integration */
+
+  float shoot_range, explosion_range, origin_range, hit_prob;
+  int32_t cooldown_steps; /* 4 s / (1/15 s) = 60 (gun.py:25) */
+  int32_t munition;       /* per pursuer (20 in exp02/03; 4 for the stage02 agent; 0 in stage01) */
+  int32_t max_step;       /* 300 (level4, stage01), 600 (stage02) */
+  int32_t step_increment; /* +100 per step with >= 1 successful shot (exp03_vFinal_task.py:150-153) */
+  int32_t n_rounds;       /* waves; = calculate_rounds(P, munition) (exp03_vFinal_task.py:198-226) */
+  float born_radius;      /* 6 */
+  float born_min_z;       /* 4 */
+  float pursuer_spawn_radius; /* 2 (level4), 1 (stage02) */
+  float invader_speed;    /* 0.4 kamikaze (…air_combat_only.py:58); 0.5 hover magnitude in stage02 */
+  float ally_speed;       /* 0.6 (loyalwingman_navigator.py:37) */
+  int32_t ally_policy;    /* TE_ALLY_* */
+  float approach_bonus_gain; /* 1 (exp02/03), 10 (exp04, stage01, stage02) */
+  float catch_distance;   /* stage01: 0.4 */
+  float building_position[3]; /* (0,0,0.1) */
+
+  int32_t motor_noise;    /* 0/1 */
+  int32_t auto_reset;     /* 1: VecEnv semantics (reset inside step when done) */
+  int32_t kamikaze_cone_check; /* 0: air-combat-only navigator (_is_building_path_clear == False, used by every
+                                  vFinal task); 1: cone test of loitering_munition_navigator.py:78-87 */
+  int32_t reserved[5];
+
+  te_quad_params quad;
+} te_config;
+
+/* ---- state blob (te_get_state / te_set_state) ----------------------------
+ * Env-major array of 4-byte words: for env e,
+ *   drone d (0..D-1, pursuers first): TE_DRONE_WORDS words at (e*D + d)*TE_DRONE_WORDS
+ *   then, after all N*D drone records, env record e: TE_ENV_WORDS words.
+ * Words are float32 unless marked i32 (raw two's complement int32). */
+enum {
+  TE_D_POS = 0,        /* 3  world position */
+  TE_D_QUAT = 3,       /* 4  x,y,z,w (Bullet convention) */
+  TE_D_VEL = 7,        /* 3  world linear velocity */
+  TE_D_OMEGA = 10,     /* 3  world angular velocity */
+  TE_D_THROTTLE = 13,  /* 4  motor throttles */
+  TE_D_PID_AV_I = 17,  /* 3  angular-velocity PID integral */
+  TE_D_PID_AV_E = 20,  /* 3  angular-velocity PID previous error */
+  TE_D_PID_LV_I = 23,  /* 2  linear-velocity PID integral */
+  TE_D_PID_LV_E = 25,  /* 2  linear-velocity PID previous error */
+  TE_D_PID_ZV_I = 27,  /* 1 */
+  TE_D_PID_ZV_E = 28,  /* 1 */
+  TE_D_SETPOINT = 29,  /* 4  [vx, vy, vr, vz] (mode 6) or [x, y, r, z] (mode 7) */
+  TE_D_OBS_POS = 33,   /* 3  last IMU read: position (imu.py:27-41) */
+  TE_D_OBS_EULER = 36, /* 3  roll, pitch, yaw */
+  TE_D_OBS_VEL = 39,   /* 3  body-frame linear velocity */
+  TE_D_OBS_RATE = 42,  /* 3  body-frame angular velocity */
+  TE_D_FORMATION = 45, /* 3  last replace() position (quadcopter.py:437) */
+  TE_D_PENDING = 48,   /* 6  world force(3)+torque(3) applied outside the loop, consumed by the next
+                             integration (stage01 replace_invader, level2/components/quadcopter_manager.py:166-179) */
+  TE_D_ARMED = 54,     /* i32 */
+  TE_D_MUNITION = 55,  /* i32 */
+  TE_D_LAST_FIRED = 56,/* i32 */
+  TE_D_NAV_STATE = 57, /* i32 TE_NAV_* */
+  TE_DRONE_WORDS = 58
+};
+enum {
+  TE_E_STEP = 0,         /* i32 RL step counter of the episode */
+  TE_E_MAX_STEP = 1,     /* i32 */
+  TE_E_ROUND = 2,        /* i32 current wave */
+  TE_E_LAST_DIST = 3,    /* f32 last_closest_distance (level4) / last_distance (stage01) */
+  TE_E_AGENT_KILLS = 4,  /* i32 */
+  TE_E_ALLIES_KILLS = 5, /* i32 */
+  TE_E_DEADS = 6,        /* i32 */
+  TE_E_SNAP_MASK = 7,    /* i32 bit d = drone d was armed when the offsets were last computed
+                                (level4/components/entities_management/offsets_handler.py:68-95) */
+  TE_E_EPISODE = 8,      /* i32 episode counter (RNG stream selector) */
+  TE_E_LAST_ACTION = 9,  /* 4 f32 */
+  TE_E_PREV_SNAP_MIN = 13, /* f32 stage02: last_closest_pursuer_to_invader_distance */
+  TE_E_SPARE = 14,
+  TE_ENV_WORDS = 16
+};
+
+typedef struct te_env te_env; /* opaque */
+
+/* Fill `cfg` with the reference constants of `task` (n_envs = 1, seed = 0).
+ * Mirrors Task.init_constants (exp03_vFinal_task.py:88-112, level3/components/stages.py:65-83,
+ * level2/pyflyt_level2_environment_modified_v2.py:27-47). */
+int te_config_default(te_config* cfg, int32_t task);
+
+/* Replaces N x `Env.__init__` (exp03_vFinal_environment.py:42-63): allocates HBM state for
+ * cfg->n_envs environments on `device_id` and runs on_env_init + on_episode_start. */
+int te_create(const te_config* cfg, int32_t device_id, te_env** out);
+void te_destroy(te_env* env);
+
+/* Replaces `Env.reset` (exp03_vFinal_environment.py:128-146) for every env whose
+ * env_mask byte is non-zero (NULL = all).  env_mask is a device pointer of n_envs bytes. */
+int te_reset(te_env* env, const uint8_t* env_mask, void* stream);
+
+/* Replaces `Env.compute_observation` (exp03_vFinal_environment.py:200-228) without stepping:
+ * obs_lidar [N,3,13,26], obs_inertial [N,15], obs_last_action [N,4] (float32, device).
+ * Immediately after te_create/te_reset the LIDAR plane is the empty sphere (all ones). */
+int te_observe(te_env* env, float* obs_lidar, float* obs_inertial, float* obs_last_action, void* stream);
+
+/* Replaces `VecEnv.step_async + step_wait` over N x `Env.step`
+ * (exp03_vFinal_environment.py:150-171; SB3 auto-reset when cfg.auto_reset).
+ *   actions        [N,4] float32 (direction xyz in [-1,1], magnitude in [0,1])
+ *   reward [N] f32, done [N] u8, info [N,4] i32
+ *   terminal_*     may be NULL; rows are written ONLY for envs with done != 0
+ *                  (SB3 infos[i]["terminal_observation"]). */
+int te_step(te_env* env, const float* actions, float* obs_lidar, float* obs_inertial,
+            float* obs_last_action, float* reward, uint8_t* done, int32_t* info,
+            float* terminal_lidar, float* terminal_inertial, float* terminal_last_action,
+            void* stream);
+
+/* Synthetic random-action generator of the throughput harness
+ * (apps/threatengage_runner/interactive/analyse.py:55-59): dir ~ U(-1,1)^3, mag ~ U(0,1),
+ * Philox4x32-10 keyed on (seed, global env index, step_index). */
+int te_random_actions(te_env* env, float* actions, uint64_t seed, uint64_t step_index, void* stream);
+
+/* Checkpoint / parity hooks (the reference never checkpoints env state). */
+int te_state_words(const te_env* env, size_t* out_words);
+int te_get_state(te_env* env, void* dst_device, size_t words, void* stream);
+int te_set_state(te_env* env, const void* src_device, size_t words, void* stream);
+
+/* Algorithmic HBM bytes one te_step moves per environment (SURVEY.md 8(d) formula). */
+int te_algorithmic_bytes_per_env_step(const te_config* cfg, size_t* out_bytes);
+
+/* Time the kernels of the most recent te_step with HIP events recorded on its stream:
+ * out_ms[0] = sub-step kernel, out_ms[1] = engage/observe kernel.  Blocks until they finish. */
+int te_last_step_kernel_ms(te_env* env, float out_ms[2]);
+
+int te_abi_version(void);
+const char* te_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THREATENGAGE_H */
