@@ -1,0 +1,53 @@
+"""Build dronechase_amd/libthreatengage.so in-tree with hipcc for gfx950 (no JIT cache, no pip)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libthreatengage.so")
+SOURCES = ["te_env.hip", "te_config.c"]
+DEPS = ["te_env.hip", "te_config.c", "te_device.hpp", os.path.join("..", "..", "include", "threatengage.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    if not force and not needs_build():
+        return LIB
+    hipcc = _hipcc()
+    obj = os.path.join(CSRC, "te_config.o")
+    subprocess.run(["gcc", "-O2", "-fPIC", "-fvisibility=hidden", "-c", os.path.join(CSRC, "te_config.c"), "-o", obj],
+                   check=True)
+    hobj = os.path.join(CSRC, "te_env.o")
+    compile_cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-gpu-rdc",
+                   "-Wall", "-Wno-unused-function", *extra_flags, "-c", os.path.join(CSRC, "te_env.hip"), "-o", hobj]
+    link_cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", hobj, obj, "-o", LIB + ".tmp", "-lm"]
+    for cmd in (compile_cmd, link_cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    os.remove(hobj)
+    os.replace(LIB + ".tmp", LIB)
+    os.remove(obj)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))
