@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Throughput harness of the hot path: random-action rollouts of the stage03 environment
+(level4 exp03-vFinal: 2 pursuers + 9 invaders, own-sphere LIDAR) on N MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one env.step() of every environment of the rank's shard: device-side synthetic actions
+(dir ~ U(-1,1)^3, mag ~ U(0,1), Philox; mirrors apps/threatengage_runner/interactive/analyse.py:55-59)
+followed by te_step (two HIP kernels).  Environments shard across ranks with no data-path collective
+(weak scaling: --envs-per-gpu is fixed); RNG is keyed on the GLOBAL env index.  Rank 0 prints ONE JSON
+line.  Inputs and outputs stay resident in HBM for the whole timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--task", default="stage03", help="stage01 | stage02 | exp02 | stage03 (= exp03) | exp04")
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--n-invaders", type=int, default=0, help="override I (stage02 with 8 invaders: --n-invaders 8)")
+    ap.add_argument("--no-noise", action="store_true", help="motor noise off (parity runs); default on")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--action-seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-profile-events", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(task: str, overrides: dict, action_seed: int, seconds: float):
+    """The oracle (scalar C restatement, float64, OpenMP over envs) timed on this box's host cores on a
+    bounded sample of the same workload.  A reported baseline, not the optimisation target."""
+    from oracle import te_oracle as O
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = 4096
+    cfg = O.default_config(task, n_envs=n, **overrides)
+    env = O.OracleEnv(cfg, "f64", threads=cores)
+    env.reset()
+    for s in range(3):
+        env.step(env.random_actions(action_seed, s), terminal=False)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        env.step(env.random_actions(action_seed, 3 + steps), terminal=False)
+        steps += 1
+        if (time.perf_counter() - t0 >= seconds and steps >= 10) or steps >= 2000:
+            break
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {steps} env-steps of the same task, random actions, motor noise "
+                      f"{'on' if cfg.motor_noise else 'off'}, float64 C restatement with OpenMP ({dt:.1f} s); "
+                      "PyBullet/PyFlyt are not installable here (no reference build possible)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from dronechase_amd import _lib, default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    from dronechase_amd.build import build_library
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if rank == 0:
+        build_library()  # no-op when dronechase_amd/libthreatengage.so is up to date
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: dronechase_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)  # barrier + max-over-ranks only; no data-path collective
+        dist.barrier()
+
+    overrides = dict(motor_noise=0 if args.no_noise else 1, seed=args.seed)
+    if args.n_invaders:
+        overrides["n_invaders"] = args.n_invaders
+    n_local = args.envs_per_gpu
+    cfg = default_config(args.task, n_envs=n_local, env_index_base=rank * n_local, **overrides)
+    env = BatchedEnv(cfg, device)
+    actions = torch.empty((n_local, 4), dtype=torch.float32, device=device)
+
+    def one_step(i: int):
+        env.random_actions(args.action_seed, i, out=actions)
+        env.step(actions, terminal=True)
+
+    env.reset()
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize(device)
+    use_events = not args.no_profile_events
+    if use_events:
+        env.profile_begin(args.steps)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    k1_ms, k2_ms, n_prof = env.profile_end() if use_events else (0.0, 0.0, 0)
+    done_frac = float(env.done.float().mean().item())
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        D = cfg.n_drones
+        total_env_steps = world * n_local * args.steps
+        value = total_env_steps / elapsed
+        alg = _lib.algorithmic_bytes_per_env_step(cfg)          # whole env.step
+        alg_k1 = D * 2 * 176 + 16                                 # state planes read + written, action read
+        alg_k2 = alg - alg_k1                                     # env scalars r/w + observation written
+        out = {
+            "metric": "env-steps/sec (whole job), random-action rollout",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.task} (level4 exp03-vFinal shape: {cfg.n_pursuers} pursuers + {cfg.n_invaders} "
+                                   f"invaders, own-sphere LIDAR 3x13x26), {n_local} envs per GPU, 16 physics sub-steps per env-step, "
+                                   f"random actions, motor noise {'on' if cfg.motor_noise else 'off'}, auto-reset on",
+                       "task": args.task, "envs_per_gpu": n_local, "total_envs": world * n_local, "drones_per_env": D,
+                       "parallelism": f"env-sharded x{world}, no collective"},
+            "done_fraction_last_step": done_frac,
+        }
+        if use_events and n_prof:
+            dom_ms, dom_name, dom_bytes = max((k1_ms, "substeps_kernel", alg_k1), (k2_ms, "engage_observe_kernel", alg_k2))
+            ach = dom_bytes * n_local / (dom_ms * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(dom_name, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": dom_bytes * n_local, "avg_launch_ms": dom_ms,
+                               "launches_timed": n_prof}
+            step_ms = k1_ms + k2_ms
+            out["roofline_env_step"] = {"bound": "hbm", "achieved": alg * n_local / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": alg * n_local / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "algorithmic_bytes_per_env_step": alg, "substeps_kernel_ms": k1_ms,
+                                        "engage_observe_kernel_ms": k2_ms}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.task, overrides, args.action_seed, args.cpu_seconds)
+            except Exception as exc:  # the baseline is a reported extra: never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
