@@ -1,0 +1,76 @@
+"""Single-environment classes with the reference's names and constructor signature
+`(dome_radius, rl_frequency, GUI)`: gymnasium-style reset(seed) -> (obs, info), step(a) -> 5-tuple.
+
+They are N=1 views of the batched GPU environment (no separate implementation); for throughput use
+ThreatEngageVecEnv / create_vectorized_environment."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import spaces
+from .vec_env import INFO_KEYS, make_config
+
+
+class _SingleEnv:
+    TASK = "stage03"
+    DEFAULT_DOME = 20.0
+
+    def __init__(self, dome_radius: Optional[float] = None, rl_frequency: int = 15, GUI: bool = False,
+                 device: str = "cuda:0", seed: int = 0, **overrides):
+        if GUI:
+            raise ValueError("GUI rendering is out of scope (PyBullet debug window)")
+        from .batched_env import BatchedEnv
+
+        self.dome_radius = self.DEFAULT_DOME if dome_radius is None else float(dome_radius)
+        self.rl_frequency = rl_frequency
+        self.cfg = make_config(self.TASK, 1, self.dome_radius, rl_frequency, seed, auto_reset=0, **overrides)
+        self._b = BatchedEnv(self.cfg, device)
+        self.action_space = spaces.action_space()
+        self.observation_space = spaces.observation_space()
+
+    def _obs(self, lidar, inertial, last_action):
+        return {"lidar": lidar[0].cpu().numpy(), "inertial_data": inertial[0].cpu().numpy(),
+                "last_action": last_action[0].cpu().numpy()}
+
+    def reset(self, seed=0, options=None):
+        """`seed` is accepted and ignored, as in the reference (exp03_vFinal_environment.py:128-146)."""
+        return self._obs(*self._b.reset()), {}
+
+    def step(self, rl_action: np.ndarray):
+        import torch
+
+        a = torch.as_tensor(np.asarray(rl_action, np.float32).reshape(1, 4), device=self._b.device)
+        lidar, inertial, last_action, reward, done, info = self._b.step(a, terminal=False)
+        inf = dict(zip(INFO_KEYS, (int(v) for v in info[0].cpu().numpy())))
+        return self._obs(lidar, inertial, last_action), float(reward[0].item()), bool(done[0].item()), False, inf
+
+    def close(self):
+        self._b.close()
+
+
+class Exp02vFinalEnvironment(_SingleEnv):  # level4/exp02_vFinal_environment.py:30
+    TASK = "exp02"
+
+
+class Exp03vFinalEnvironment(_SingleEnv):  # level4/exp03_vFinal_environment.py:28
+    TASK = "exp03"
+
+
+class Exp04vFinalEnvironment(_SingleEnv):  # level4/exp04_vFinal_environment.py:22
+    TASK = "exp04"
+
+
+class PyflytL2EnviromentModifiedV2(_SingleEnv):  # level2/pyflyt_level2_environment_modified_v2.py:15 (sic)
+    TASK = "stage01"
+    DEFAULT_DOME = 10.0
+
+
+class PyflytL3EnviromentV2(_SingleEnv):  # level3/pyflyt_level3_environment_v2.py:20 (sic)
+    TASK = "stage02"
+    DEFAULT_DOME = 8.0
+
+
+ENV_TASKS = {cls: cls.TASK for cls in (Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment,
+                                       PyflytL2EnviromentModifiedV2, PyflytL3EnviromentV2)}

@@ -1,0 +1,207 @@
+"""ThreatEngageVecEnv — the drop-in for the object `ReinforcementLearningPipeline.create_vectorized_environment`
+returns (src/core/rl_framework/utils/pipeline.py:31-61): the SB3 2.6 `VecEnv` surface over ONE batched GPU
+environment instead of N SubprocVecEnv workers.
+
+SB3 is not required: the class is duck-typed, and additionally derives from
+stable_baselines3.common.vec_env.VecEnv when that package is importable so isinstance checks pass."""
+from __future__ import annotations
+
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import config as K
+from . import spaces
+from ._lib import default_config
+
+try:  # pragma: no cover - depends on the box
+    from stable_baselines3.common.vec_env.base_vec_env import VecEnv as _SB3VecEnv  # type: ignore
+except Exception:
+    _SB3VecEnv = object
+
+INFO_KEYS = ("agent_kills", "allies_kills", "deads", "current_wave")  # exp03_vFinal_task.py:571-578
+
+
+def make_config(task: str, num_envs: int, dome_radius: Optional[float] = None, rl_frequency: int = 15, seed: int = 0,
+                env_index_base: int = 0, **overrides) -> K.Config:
+    """Reference constructor kwargs (dome_radius, rl_frequency, GUI; pipeline.py:45-51) -> te_config."""
+    cfg = default_config(task, n_envs=num_envs, seed=seed, env_index_base=env_index_base)
+    if dome_radius is not None:
+        cfg.dome_radius = float(dome_radius)
+        # lidar radius follows the dome only where the reference ties them (stages.py:397-401,
+        # exp03_vFinal_task.py:641-643); stage01 hard-codes 20 (level2/components/quadcopter_manager.py:44)
+        if cfg.task != K.TASK_STAGE01:
+            cfg.lidar_radius = 2.0 * float(dome_radius)
+    if rl_frequency != 15:
+        agg = int(120 / rl_frequency)  # frequency_adjustments (exp03_vFinal_environment.py:107-110)
+        if agg < 1:
+            raise ValueError("rl_frequency must be <= 120")
+        cfg.substeps = 2 * agg
+        if cfg.task == K.TASK_STAGE01:
+            cfg.max_step = 20 * rl_frequency  # pyflyt_level2_environment_modified_v2.py:47
+    return K.apply_overrides(cfg, **overrides)
+
+
+class LazyInfos(Sequence):
+    """infos without materialising N dicts per step: dicts are built on access."""
+
+    def __init__(self, info: np.ndarray, done: np.ndarray, terminal: Optional[Dict[str, np.ndarray]]):
+        self._info, self._done, self._terminal = info, done, terminal
+
+    def __len__(self):
+        return len(self._done)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        d = dict(zip(INFO_KEYS, (int(v) for v in self._info[i])))
+        d["TimeLimit.truncated"] = False  # the reference always returns truncated=False (exp03_vFinal_environment.py:167)
+        if self._done[i] and self._terminal is not None:
+            d["terminal_observation"] = {k: v[i] for k, v in self._terminal.items()}
+        return d
+
+
+class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
+    """SB3 VecEnv API: reset / step_async / step_wait / step / close / seed / get_attr / set_attr /
+    env_method / env_is_wrapped, attributes num_envs, observation_space, action_space, reset_infos,
+    render_mode.  Auto-reset with infos[i]["terminal_observation"] as SB3 expects."""
+
+    def __init__(self, task: str = "stage03", num_envs: int = 1024, device: str = "cuda:0",
+                 dome_radius: Optional[float] = None, rl_frequency: int = 15, GUI: bool = False, seed: int = 0,
+                 env_index_base: int = 0, output: str = "numpy", infos: str = "dicts", backend=None, **overrides):
+        if GUI:
+            raise ValueError("GUI=True has no batched equivalent (the reference forces n_envs=1 with a PyBullet window)")
+        if output not in ("numpy", "torch") or infos not in ("dicts", "lazy"):
+            raise ValueError("output in {'numpy','torch'}, infos in {'dicts','lazy'}")
+        self.task = task
+        self.cfg = make_config(task, num_envs, dome_radius, rl_frequency, seed, env_index_base, auto_reset=1, **overrides)
+        self.output, self.infos_mode = output, infos
+        if backend is None:
+            from .batched_env import BatchedEnv  # imports torch; fails loudly without a GPU
+            backend = BatchedEnv(self.cfg, device)
+        self.backend = backend
+        self.num_envs = int(num_envs)
+        self.observation_space = spaces.observation_space()
+        self.action_space = spaces.action_space()
+        self.render_mode = None
+        self.reset_infos: List[Dict[str, Any]] = [{} for _ in range(self.num_envs)]
+        self._actions = None
+        self._seeds: List[Optional[int]] = [None] * self.num_envs
+        self._options: List[Dict[str, Any]] = [{} for _ in range(self.num_envs)]
+        self.metadata = {"render_modes": []}
+
+    # ------------------------------------------------------------------ helpers
+    def _to_out(self, t):
+        return t if self.output == "torch" else t.detach().cpu().numpy()
+
+    def _obs(self, lidar, inertial, last_action):
+        return {"lidar": self._to_out(lidar), "inertial_data": self._to_out(inertial), "last_action": self._to_out(last_action)}
+
+    def _as_device_actions(self, actions):
+        import torch
+
+        b = self.backend
+        if isinstance(actions, torch.Tensor):
+            return actions.to(device=b.device, dtype=torch.float32).reshape(self.num_envs, 4)
+        a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 4)
+        return torch.from_numpy(np.ascontiguousarray(a)).to(b.device)
+
+    # ------------------------------------------------------------------ VecEnv API
+    def reset(self):
+        lidar, inertial, last_action = self.backend.reset()
+        self.reset_infos = [{} for _ in range(self.num_envs)]
+        self._seeds = [None] * self.num_envs
+        self._options = [{} for _ in range(self.num_envs)]
+        return self._obs(lidar, inertial, last_action)
+
+    def step_async(self, actions) -> None:
+        self._actions = self._as_device_actions(actions)
+
+    def step_wait(self):
+        if self._actions is None:
+            raise RuntimeError("step_wait() without step_async()")
+        b = self.backend
+        lidar, inertial, last_action, reward, done, info = b.step(self._actions, terminal=True)
+        self._actions = None
+        obs = self._obs(lidar, inertial, last_action)
+        done_np = done.detach().cpu().numpy().astype(bool)
+        info_np = info.detach().cpu().numpy()
+        terminal = None
+        if done_np.any():
+            if self.output == "torch":
+                terminal = {"lidar": b.t_lidar, "inertial_data": b.t_inertial, "last_action": b.t_last_action}
+            else:  # copy only the rows that are valid
+                idx = np.flatnonzero(done_np)
+                import torch
+
+                ti = torch.from_numpy(idx).to(b.device)
+                rows = {"lidar": b.t_lidar[ti].cpu().numpy(), "inertial_data": b.t_inertial[ti].cpu().numpy(),
+                        "last_action": b.t_last_action[ti].cpu().numpy()}
+                terminal = {k: _ScatterRows(idx, v, self.num_envs) for k, v in rows.items()}
+        infos = LazyInfos(info_np, done_np, terminal)
+        if self.infos_mode == "dicts":
+            infos = list(infos)
+        rew = self._to_out(reward)
+        dones = done.bool() if self.output == "torch" else done_np
+        return obs, rew, dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self) -> None:
+        if self.backend is not None:
+            self.backend.close()
+
+    def seed(self, seed: Optional[int] = None):
+        """The reference ignores seeds (exp03_vFinal_environment.py:128 `reset(self, seed=0)`); here the seed
+        is fixed at construction because it keys the device RNG.  Returns the per-env list SB3 expects."""
+        return [None] * self.num_envs
+
+    def _indices(self, indices) -> Iterable[int]:
+        if indices is None:
+            return range(self.num_envs)
+        if isinstance(indices, int):
+            return [indices]
+        return indices
+
+    def get_attr(self, attr_name: str, indices=None) -> List[Any]:
+        n = len(list(self._indices(indices)))
+        if attr_name == "render_mode":
+            return [None] * n
+        if hasattr(self, attr_name):
+            return [getattr(self, attr_name)] * n
+        raise AttributeError(attr_name)
+
+    def set_attr(self, attr_name: str, value: Any, indices=None) -> None:
+        raise AttributeError(f"per-env attribute {attr_name!r} cannot be set on a batched environment")
+
+    def env_method(self, method_name: str, *method_args, indices=None, **method_kwargs) -> List[Any]:
+        raise AttributeError(f"per-env method {method_name!r} is not available on a batched environment")
+
+    def env_is_wrapped(self, wrapper_class, indices=None) -> List[bool]:
+        return [False] * len(list(self._indices(indices)))
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def render(self, mode: Optional[str] = None):
+        return None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def __len__(self):
+        return self.num_envs
+
+
+class _ScatterRows:
+    """Read-only view mapping env index -> row of a compact [n_done, ...] array."""
+
+    def __init__(self, idx: np.ndarray, rows: np.ndarray, n: int):
+        self._pos = {int(e): k for k, e in enumerate(idx)}
+        self._rows = rows
+
+    def __getitem__(self, env: int):
+        return self._rows[self._pos[int(env)]]

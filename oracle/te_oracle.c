@@ -68,7 +68,8 @@ typedef struct ote_env {
   int D;
   ote_drone* drones; /* [N*D] */
   ote_envrec* envs;  /* [N] */
-  real* margin;      /* [N] min |value - threshold| over the discrete decisions of the last step */
+  real* margin;      /* [N] min |value - threshold| over ALL discrete decisions of the last step */
+  real* margin_state; /* [N] same, restricted to decisions that change state or done (not reward-only ones) */
 } ote_env;
 
 /* ------------------------------------------------------------------------- */
@@ -855,6 +856,11 @@ static void note_margin(real* m, real value, real threshold) {
   real d = fabs(value - threshold);
   if (d < *m) *m = d;
 }
+/* decision that changes state / done: recorded in both margins (m[0] = all, m[1] = state) */
+static void note_state_margin(real m[2], real value, real threshold) {
+  note_margin(&m[0], value, threshold);
+  note_margin(&m[1], value, threshold);
+}
 
 /* One env.step of the level4 family (exp03_vFinal_environment.py:150-171). */
 static void level4_step_env(ote_env* E, int e, const float* action, float* lidar, float* inertial, float* last_action,
@@ -864,7 +870,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   const int D = E->D, P = c->n_pursuers;
   ote_drone* dr = &E->drones[(size_t)e * D];
   ote_envrec* er = &E->envs[e];
-  real margin = (real)1e30;
+  real mg[2] = {(real)1e30, (real)1e30};
 
   /* (1) agent command (quadcopter.py:398-413) */
   real cmd[4] = {(real)action[0], (real)action[1], (real)action[2], (real)action[3]};
@@ -906,7 +912,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
     for (int j = P; j < D; ++j) {
       if (!((S >> j) & 1u)) continue;
       real d = dist3(dr[p].obs_pos, dr[j].obs_pos);
-      note_margin(&margin, d, (real)c->shoot_range);
+      note_state_margin(mg, d, (real)c->shoot_range);
       if (d < (real)c->shoot_range && (tgt < 0 || d < bd)) { tgt = j; bd = d; }
     }
     if (tgt < 0) continue;
@@ -924,7 +930,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
     for (int j = P; j < D; ++j) {
       if (!((S >> j) & 1u)) continue;
       real d = dist3(dr[p].obs_pos, dr[j].obs_pos);
-      note_margin(&margin, d, (real)c->explosion_range);
+      note_state_margin(mg, d, (real)c->explosion_range);
       if (d < (real)c->explosion_range && (tgt < 0 || d < bd)) { tgt = j; bd = d; }
     }
     if (tgt < 0) continue;
@@ -939,7 +945,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   for (int j = P; j < D; ++j) {
     if (!((S >> j) & 1u)) continue;
     real n = norm3(dr[j].obs_pos);
-    note_margin(&margin, n, (real)c->origin_range);
+    note_state_margin(mg, n, (real)c->origin_range);
     if (n < (real)c->origin_range) disarm(&dr[j]);
   }
 
@@ -956,7 +962,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
     if (target >= 0) { tp[0] = dr[target].obs_pos[0]; tp[1] = dr[target].obs_pos[1]; tp[2] = dr[target].obs_pos[2]; }
     real cur = dist3(ag->obs_pos, tp);
     int ready = (g[2] == (real)1) || (g[0] == (real)0);
-    note_margin(&margin, er->last_dist - cur, (real)0.01);
+    note_margin(&mg[0], er->last_dist - cur, (real)0.01);
     if ((real)0.01 < er->last_dist - cur && ready) bonus += (real)c->approach_bonus_gain * norm3(ag->obs_vel);
     er->last_dist = cur;
     score = ready ? -cur : cur * ((real)2 * g[1] - (real)1);
@@ -964,17 +970,17 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
     if (agent_shots > 0 || agent_suicided > 0) bonus += (real)(agent_shots + agent_suicided) * MAXR;
     if (ally_shots > 0 || pursuer_suicided > 0) bonus += (real)0.5 * (real)(ally_shots + pursuer_suicided) * MAXR;
     else if (exploded > 0) penalty += MAXR * (real)exploded;
-    note_margin(&margin, ag->obs_pos[2], (real)-5);
+    note_margin(&mg[0], ag->obs_pos[2], (real)-5);
     if (ag->obs_pos[2] < (real)-5) penalty += ((real)-5 - ag->obs_pos[2]) / (real)1 * MAXR;
     int outside = 0;
     for (int p = 0; p < P; ++p)
       if ((S >> p) & 1u) {
         real n = norm3(dr[p].obs_pos);
-        note_margin(&margin, n, (real)c->dome_radius);
+        note_state_margin(mg, n, (real)c->dome_radius);
         if (n > (real)c->dome_radius) outside += 1;
       }
     if (outside > 0) penalty += MAXR;
-    note_margin(&margin, dist_origin, (real)c->born_radius - (real)2);
+    note_margin(&mg[0], dist_origin, (real)c->born_radius - (real)2);
     if (dist_origin > (real)c->born_radius - (real)2) penalty += dist_origin - (real)c->born_radius - (real)2; /* literal, SURVEY.md C8 */
   }
   real rew = score + bonus - penalty;
@@ -992,12 +998,12 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
     for (int i = 0; i < D; ++i)
       if ((S >> i) & 1u) {
         real n = norm3(dr[i].obs_pos);
-        if (i >= P) note_margin(&margin, n, (real)c->dome_radius);
+        if (i >= P) note_state_margin(mg, n, (real)c->dome_radius);
         if (n > (real)c->dome_radius) term = 1;
       }
     if (armed_pursuers == 0) term = 1;
     if (!dr[0].armed) term = 1;
-    note_margin(&margin, dr[0].obs_pos[2], (real)-5.99);
+    note_state_margin(mg, dr[0].obs_pos[2], (real)-5.99);
     if (dr[0].obs_pos[2] < (real)-5.99) term = 1;
   }
 
@@ -1027,7 +1033,8 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   *reward = (float)rew;
   *done = (uint8_t)term;
   for (int k = 0; k < 4; ++k) info[k] = inf[k];
-  E->margin[e] = margin;
+  E->margin[e] = mg[0];
+  E->margin_state[e] = mg[1];
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1083,7 +1090,7 @@ static void stage02_step_env(ote_env* E, int e, const float* action, float* lida
   const int D = E->D, P = c->n_pursuers;
   ote_drone* dr = &E->drones[(size_t)e * D];
   ote_envrec* er = &E->envs[e];
-  real margin = (real)1e30;
+  real mg[2] = {(real)1e30, (real)1e30};
   real cmd[4] = {(real)action[0], (real)action[1], (real)action[2], (real)action[3]};
   for (int k = 0; k < 4; ++k) er->last_action[k] = cmd[k];
   command_to_setpoint(cmd, dr[0].setpoint);
@@ -1112,7 +1119,7 @@ static void stage02_step_env(ote_env* E, int e, const float* action, float* lida
     for (int j = P; j < D; ++j) {
       if (!((S >> j) & 1u)) continue;
       real d = dist3(dr[p].obs_pos, dr[j].obs_pos);
-      note_margin(&margin, d, (real)c->shoot_range);
+      note_state_margin(mg, d, (real)c->shoot_range);
       if (d < (real)c->shoot_range && (tgt < 0 || d < bd)) { tgt = j; bd = d; }
     }
     if (tgt < 0) continue;
@@ -1128,7 +1135,7 @@ static void stage02_step_env(ote_env* E, int e, const float* action, float* lida
     for (int j = P; j < D; ++j) {
       if (!((S >> j) & 1u)) continue;
       real d = dist3(dr[p].obs_pos, dr[j].obs_pos);
-      note_margin(&margin, d, (real)c->explosion_range);
+      note_state_margin(mg, d, (real)c->explosion_range);
       if (d < (real)c->explosion_range && (tgt < 0 || d < bd)) { tgt = j; bd = d; }
     }
     if (tgt < 0) continue;
@@ -1144,7 +1151,7 @@ static void stage02_step_env(ote_env* E, int e, const float* action, float* lida
   if (g[2] == (real)1) score = -cur;
   else if (g[0] == (real)0) score = -cur;
   else score = cur * ((real)2 * g[1] - (real)1);
-  note_margin(&margin, last - cur, (real)0.01);
+  note_margin(&mg[0], last - cur, (real)0.01);
   if ((real)0.01 < last - cur && (g[2] == (real)1 || g[0] == (real)0))
     bonus += (real)c->approach_bonus_gain * norm3(dr[0].obs_vel);
   bonus += (real)1000 * (real)shots;
@@ -1153,7 +1160,7 @@ static void stage02_step_env(ote_env* E, int e, const float* action, float* lida
   for (int i = 0; i < D; ++i)
     if ((S >> i) & 1u) {
       real n = norm3(dr[i].obs_pos);
-      note_margin(&margin, n, (real)c->dome_radius);
+      note_state_margin(mg, n, (real)c->dome_radius);
       if (n > (real)c->dome_radius) { if (i < P) outside_p += 1; else outside_i += 1; }
     }
   if (outside_p > 0) penalty += (real)1000;
@@ -1186,7 +1193,8 @@ static void stage02_step_env(ote_env* E, int e, const float* action, float* lida
   }
   *reward = (float)rew; *done = (uint8_t)term;
   info[0] = er->agent_kills; info[1] = 0; info[2] = er->deads; info[3] = 0;
-  E->margin[e] = margin;
+  E->margin[e] = mg[0];
+  E->margin_state[e] = mg[1];
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1243,7 +1251,7 @@ static void stage01_step_env(ote_env* E, int e, const float* action, float* lida
   const int D = E->D;
   ote_drone* dr = &E->drones[(size_t)e * D];
   ote_envrec* er = &E->envs[e];
-  real margin = (real)1e30;
+  real mg[2] = {(real)1e30, (real)1e30};
   er->step += 1; /* step_calls += 1 (:128) */
   real cmd[4] = {(real)action[0], (real)action[1], (real)action[2], (real)action[3]};
   for (int k = 0; k < 4; ++k) er->last_action[k] = cmd[k];
@@ -1257,16 +1265,16 @@ static void stage01_step_env(ote_env* E, int e, const float* action, float* lida
   float* L; float* In; float* La;
   real d = dist3(dr[2].obs_pos, dr[0].obs_pos);
   real bonus = 0, penalty = 0;
-  note_margin(&margin, d, er->last_dist);
+  note_margin(&mg[0], d, er->last_dist);
   if (d < er->last_dist) bonus += (real)c->approach_bonus_gain * norm3(dr[0].obs_vel);
-  note_margin(&margin, d, (real)c->catch_distance);
+  note_state_margin(mg, d, (real)c->catch_distance);
   if (d < (real)c->catch_distance) bonus += (real)1000;
-  note_margin(&margin, d, (real)c->dome_radius);
+  note_state_margin(mg, d, (real)c->dome_radius);
   if (d > (real)c->dome_radius) penalty += (real)1000;
   real rew = -d + bonus - penalty;
   real n0 = norm3(dr[0].obs_pos), n2 = norm3(dr[2].obs_pos);
-  note_margin(&margin, n0, (real)c->dome_radius);
-  note_margin(&margin, n2, (real)c->dome_radius);
+  note_state_margin(mg, n0, (real)c->dome_radius);
+  note_state_margin(mg, n2, (real)c->dome_radius);
   int term = (er->step > er->max_step) || n0 > (real)c->dome_radius || n2 > (real)c->dome_radius;
   L = term && t_lidar ? t_lidar : lidar;
   In = term && t_inertial ? t_inertial : inertial;
@@ -1290,7 +1298,8 @@ static void stage01_step_env(ote_env* E, int e, const float* action, float* lida
   }
   *reward = (float)rew; *done = (uint8_t)term;
   info[0] = er->agent_kills; info[1] = 0; info[2] = 0; info[3] = 0;
-  E->margin[e] = margin;
+  E->margin[e] = mg[0];
+  E->margin_state[e] = mg[1];
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1313,13 +1322,14 @@ OTE_API ote_env* ote_create(const te_config* cfg) {
   E->drones = (ote_drone*)calloc((size_t)cfg->n_envs * D, sizeof(ote_drone));
   E->envs = (ote_envrec*)calloc((size_t)cfg->n_envs, sizeof(ote_envrec));
   E->margin = (real*)calloc((size_t)cfg->n_envs, sizeof(real));
+  E->margin_state = (real*)calloc((size_t)cfg->n_envs, sizeof(real));
   for (size_t i = 0; i < (size_t)cfg->n_envs * D; ++i) E->drones[i].quat[3] = 1;
   for (int e = 0; e < cfg->n_envs; ++e) reset_env(E, e);
   return E;
 }
 OTE_API void ote_destroy(ote_env* E) {
   if (!E) return;
-  free(E->drones); free(E->envs); free(E->margin); free(E);
+  free(E->drones); free(E->envs); free(E->margin); free(E->margin_state); free(E);
 }
 OTE_API int ote_real_bytes(void) { return (int)sizeof(real); }
 OTE_API int ote_reset(ote_env* E, const uint8_t* mask) {
@@ -1367,6 +1377,10 @@ OTE_API int ote_step(ote_env* E, const float* actions, float* lidar, float* iner
 }
 OTE_API int ote_margins(const ote_env* E, double* out) {
   for (int e = 0; e < E->cfg.n_envs; ++e) out[e] = (double)E->margin[e];
+  return 0;
+}
+OTE_API int ote_state_margins(const ote_env* E, double* out) {
+  for (int e = 0; e < E->cfg.n_envs; ++e) out[e] = (double)E->margin_state[e];
   return 0;
 }
 /* synthetic actions: dir ~ U(-1,1)^3, mag ~ U(0,1) (apps/threatengage_runner/interactive/analyse.py:55-59) */

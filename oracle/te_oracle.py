@@ -40,6 +40,7 @@ def lib(precision: str = "f64") -> C.CDLL:
         L.ote_observe.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         L.ote_step.argtypes = [C.c_void_p] + [C.c_void_p] * 10 + [C.c_int]
         L.ote_margins.argtypes = [C.c_void_p, C.c_void_p]
+        L.ote_state_margins.argtypes = [C.c_void_p, C.c_void_p]
         L.ote_random_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
         L.te_config_default.argtypes = [C.POINTER(K.Config), C.c_int32]
         L.ote_degrees_between.restype = C.c_double
@@ -118,6 +119,12 @@ class OracleEnv:
     def margins(self) -> np.ndarray:
         out = np.empty(self.N, np.float64)
         self.L.ote_margins(self.h, _p(out))
+        return out
+
+    def state_margins(self) -> np.ndarray:
+        """Like margins() but only over decisions that change state or done (not reward-only thresholds)."""
+        out = np.empty(self.N, np.float64)
+        self.L.ote_state_margins(self.h, _p(out))
         return out
 
     def random_actions(self, seed: int, step_index: int) -> np.ndarray:

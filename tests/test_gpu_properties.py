@@ -1,0 +1,144 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full sizes (65 536 stage03 envs,
+16 384 stage02 envs with 8 invaders, 4 096 stage01 envs): run on an MI355X with `pytest -m gpu`.
+
+These do not need the oracle (which would take minutes at this size): determinism, shard invariance,
+observation invariants, bookkeeping identities between outputs and the state blob."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FULL = [("stage03", 65536, {}), ("stage02", 16384, {"n_invaders": 8}), ("stage01", 4096, {})]
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    return torch
+
+
+def _rollout(env, steps, seed=77, start=0):
+    outs = []
+    for s in range(steps):
+        a = env.random_actions(seed, start + s)
+        l, i, la, r, d, info = env.step(a)
+        outs.append((l.clone(), i.clone(), r.clone(), d.clone(), info.clone(), env.t_inertial.clone()))
+    return outs
+
+
+@pytest.mark.parametrize("task,N,over", FULL)
+def test_determinism_and_shard_invariance(task, N, over):
+    """Same seed -> bit-identical outputs; and splitting the env range over two te_env shards (as two
+    GPUs would, env_index_base = shard offset) reproduces the single-shard run bit for bit."""
+    torch = _torch()
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+
+    T = 12
+    full = BatchedEnv(default_config(task, n_envs=N, seed=3, **over), "cuda:0")
+    full.reset()
+    ref = _rollout(full, T)
+    again = BatchedEnv(default_config(task, n_envs=N, seed=3, **over), "cuda:0")
+    again.reset()
+    for a, b in zip(ref, _rollout(again, T)):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    again.close()
+    h = N // 2
+    lo = BatchedEnv(default_config(task, n_envs=h, seed=3, env_index_base=0, **over), "cuda:0")
+    hi = BatchedEnv(default_config(task, n_envs=N - h, seed=3, env_index_base=h, **over), "cuda:0")
+    lo.reset(); hi.reset()
+    for s in range(T):
+        a_lo, a_hi = lo.random_actions(77, s), hi.random_actions(77, s)
+        o_lo, o_hi = lo.step(a_lo), hi.step(a_hi)
+        for k, idx in enumerate((0, 1, 3, 4, 5)):  # lidar, inertial, reward, done, info
+            got = torch.cat([o_lo[idx], o_hi[idx]])
+            assert torch.equal(got, ref[s][(0, 1, 2, 3, 4)[k]]), f"shard mismatch in output {idx} at step {s}"
+    # a different seed must change the spawn positions
+    other = BatchedEnv(default_config(task, n_envs=256, seed=4, **over), "cuda:0")
+    assert not torch.equal(other.reset()[1], full.reset()[1][:256])
+    for e in (full, lo, hi, other):
+        e.close()
+
+
+@pytest.mark.parametrize("task,N,over", FULL)
+def test_observation_invariants(task, N, over):
+    torch = _torch()
+    from dronechase_amd import config as K, default_config
+    from dronechase_amd.batched_env import BatchedEnv
+
+    cfg = default_config(task, n_envs=N, seed=1, **over)
+    env = BatchedEnv(cfg, "cuda:0")
+    lidar, inertial, last_action = env.reset()
+    assert bool((lidar == 1).all())  # empty sphere after reset
+    assert bool((last_action == 0).all())
+    D, P = cfg.n_drones, cfg.n_pursuers
+    kills_prev = torch.zeros(N, dtype=torch.int32, device="cuda:0")
+    any_done = 0
+    for s in range(40):
+        a = env.random_actions(5, s)
+        lidar, inertial, last_action, reward, done, info = env.step(a)
+        assert bool(torch.isfinite(reward).all()) and bool(torch.isfinite(inertial).all())
+        assert bool(((lidar >= 0) & (lidar <= 1)).all())
+        assert bool(((inertial >= -1) & (inertial <= 1)).all())
+        hit = lidar[:, 0] < 1
+        # flag plane: 0.2 invader / 0.6 wingman on hits, 1 elsewhere; time plane 0.1 on hits
+        flag, tim = lidar[:, 1], lidar[:, 2]
+        assert bool(((flag[hit] - 0.2).abs().lt(1e-6) | (flag[hit] - 0.6).abs().lt(1e-6)).all())
+        assert bool((flag[~hit] == 1).all()) and bool((tim[~hit] == 1).all())
+        assert bool((tim[hit] - 0.1).abs().lt(1e-6).all())
+        assert bool((hit.flatten(1).sum(1) <= D - 1).all())
+        nd = ~done.bool()
+        assert bool((last_action[nd] == a[nd]).all())          # last_action echoes the action
+        assert bool((last_action[done.bool()] == 0).all())     # reset observation after auto-reset
+        assert bool((lidar[done.bool()] == 1).all())
+        # hits seen by the agent never exceed the armed drones of the (pre-respawn) state
+        st = env.get_state().view(torch.int32)
+        dr = st[: N * D * K.DRONE_WORDS].view(N, D, K.DRONE_WORDS)
+        armed = dr[:, :, K.D["ARMED"]]
+        assert bool(((armed == 0) | (armed == 1)).all())
+        assert bool((armed[:, 0] == 1).all())  # the agent is alive at every step boundary (dead => reset)
+        if task == "stage03":
+            # info[:,0] (agent kills) never decreases within an episode
+            same_ep = nd
+            assert bool((info[same_ep, 0] >= kills_prev[same_ep]).all())
+            kills_prev = torch.where(done.bool(), torch.zeros_like(kills_prev), info[:, 0])
+            assert bool(((info[:, 3] >= 1) & (info[:, 3] <= cfg.n_rounds)).all())
+            mun = dr[:, :P, K.D["MUNITION"]]
+            assert bool(((mun >= 0) & (mun <= cfg.munition)).all())
+        any_done += int(done.sum().item())
+        # disarmed drones are frozen: zero velocity, zero throttle
+        vel = dr[:, :, K.D["VEL"]:K.D["VEL"] + 3].view(torch.float32)
+        thr = dr[:, :, K.D["THROTTLE"]:K.D["THROTTLE"] + 4].view(torch.float32)
+        dead = armed == 0
+        assert bool((vel[dead] == 0).all()) and bool((thr[dead] == 0).all())
+        # unit quaternions
+        q = dr[:, :, K.D["QUAT"]:K.D["QUAT"] + 4].view(torch.float32)
+        assert bool(((q.pow(2).sum(-1) - 1).abs() < 1e-5).all())
+    env.close()
+
+
+def test_stage03_episode_statistics():
+    """Long random-action rollout at full size: episodes end, waves advance, kills happen, and the
+    terminal observation rows are only written for done envs."""
+    torch = _torch()
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+
+    N = 65536
+    env = BatchedEnv(default_config("stage03", n_envs=N, seed=8), "cuda:0")
+    env.reset()
+    env.t_inertial.fill_(-7.0)
+    dones = 0
+    max_wave = 0
+    total_kills = 0
+    for s in range(400):
+        _, _, _, reward, done, info = env.step(env.random_actions(2, s))
+        dones += int(done.sum().item())
+        max_wave = max(max_wave, int(info[:, 3].max().item()))
+    touched = (env.t_inertial != -7.0).any(1)
+    assert dones > N // 20 and max_wave >= 3
+    assert int(touched.sum().item()) <= dones  # terminal rows only for envs that finished at least once
+    assert int(touched.sum().item()) > 0
+    env.close()

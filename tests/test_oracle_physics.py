@@ -1,0 +1,124 @@
+"""Analytic known-answer tests of the oracle's L0 restatement (PyFlyt QuadX + Bullet free body).  These
+numbers are NOT pinned against PyBullet (absent here; DESIGN.md "parity unpinned"): they pin the
+restated algorithm against closed forms, and the Bullet math helpers against analytic rotations."""
+import numpy as np
+import pytest
+
+from oracle import te_oracle as O
+
+PREC = ["f64", "f32"]
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors: philox4x32-10
+    assert list(O.philox([0, 0, 0, 0], [0, 0])) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert list(O.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2)) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert list(O.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0])) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+@pytest.mark.parametrize("prec", PREC)
+def test_bullet_math_helpers(prec):
+    tol = 1e-12 if prec == "f64" else 1e-6
+    ident = [0, 0, 0, 1]
+    np.testing.assert_allclose(O.vec_fn("ote_quat_to_mat", ident, 9, prec), np.eye(3).ravel(), atol=tol)
+    # 90 deg about z (x,y,z,w order): x -> y
+    qz = [0, 0, np.sin(np.pi / 4), np.cos(np.pi / 4)]
+    np.testing.assert_allclose(O.rotate_vector(qz, [1, 0, 0], prec), [0, 1, 0], atol=tol)
+    qx = [np.sin(np.pi / 4), 0, 0, np.cos(np.pi / 4)]
+    np.testing.assert_allclose(O.rotate_vector(qx, [0, 1, 0], prec), [0, 0, 1], atol=tol)
+    qy = [0, np.sin(np.pi / 4), 0, np.cos(np.pi / 4)]
+    np.testing.assert_allclose(O.rotate_vector(qy, [0, 0, 1], prec), [1, 0, 0], atol=tol)
+    # euler <-> quaternion round trip, ZYX composition R = Rz(yaw) Ry(pitch) Rx(roll)
+    rng = np.random.RandomState(0)
+    for _ in range(200):
+        rpy = rng.uniform([-np.pi, -1.5, -np.pi], [np.pi, 1.5, np.pi])
+        q = O.vec_fn("ote_quat_from_euler", rpy, 4, prec)
+        assert abs(np.linalg.norm(q) - 1) < 10 * tol
+        np.testing.assert_allclose(O.vec_fn("ote_euler_from_quat", q, 3, prec), rpy, atol=30 * tol)
+        cr, sr, cp, sp, cy, sy = np.cos(rpy[0]), np.sin(rpy[0]), np.cos(rpy[1]), np.sin(rpy[1]), np.cos(rpy[2]), np.sin(rpy[2])
+        Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]]); Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+        Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+        np.testing.assert_allclose(O.vec_fn("ote_quat_to_mat", q, 9, prec).reshape(3, 3), Rz @ Ry @ Rx, atol=30 * tol)
+    # gimbal guard (pybullet getEulerFromQuaternion): pitch = +-pi/2 exactly
+    q = O.vec_fn("ote_quat_from_euler", [0.0, np.pi / 2, 0.3], 4)
+    e = O.vec_fn("ote_euler_from_quat", q, 3)
+    assert e[0] == 0 and abs(e[1] - np.pi / 2) < 1e-12
+
+
+def test_command_to_setpoint():
+    # quadcopter.py:379-396: [vx, vy, 0, vz] = magnitude * unit(direction); zero direction stays zero
+    np.testing.assert_allclose(O.vec_fn("ote_command_to_setpoint", [3, 0, 4, 0.5], 4), [0.3, 0, 0, 0.4], atol=1e-15)
+    np.testing.assert_allclose(O.vec_fn("ote_command_to_setpoint", [0, 0, 0, 0.4], 4), [0, 0, 0, 0], atol=0)
+    np.testing.assert_allclose(O.vec_fn("ote_command_to_setpoint", [0, -2, 0, 1], 4), [0, -1, 0, 0], atol=1e-15)
+
+
+def test_spawn_sampler_ranges():
+    # exp03_vFinal_task.py:584-608: r = 6 cap, theta in [0, pi) => y >= 0 ; phi in [acos(4/6), pi/2] => 0 <= z <= 4
+    rng = np.random.RandomState(1)
+    for _ in range(500):
+        u, v = rng.rand(2)
+        p = O.level4_position(6.0, 4.0, u, v)
+        assert abs(np.linalg.norm(p) - 6) < 1e-12 and p[1] >= -1e-12 and -1e-12 <= p[2] <= 4 + 1e-12
+        p = O.level4_position(2.0, 4.0, u, v)  # r < min_z: phi in [0, pi/2]
+        assert abs(np.linalg.norm(p) - 2) < 1e-12 and p[2] >= -1e-12
+    np.testing.assert_allclose(O.level4_position(6.0, 4.0, 0.0, 0.0), [6 * np.sin(np.arccos(4 / 6)), 0, 4.0], atol=1e-12)
+    np.testing.assert_allclose(O.level4_position(6.0, 4.0, 0.5, 1.0 - 1e-15), [0, 6, 0], atol=1e-9)
+
+
+@pytest.mark.parametrize("prec", PREC)
+def test_free_fall_closed_form(prec):
+    """Motors off (total_thrust = 0, no drag): semi-implicit Euler => v_n = -g n dt, z_n = z0 - g dt^2 n(n+1)/2."""
+    cfg = O.default_config("exp03", quad__total_thrust=0.0, quad__drag_coef_xyz=0.0, quad__thrust_coef=1.0)
+    n = 120
+    pos, vel, eul, thr = O.fly(cfg, 6, [0, 0, 0, 0], n, [1, 2, 50], prec)
+    dt, g = 1 / 240, 9.81
+    k = np.arange(1, n + 1)
+    tol = 1e-9 if prec == "f64" else 2e-4
+    np.testing.assert_allclose(vel[:, 2], -g * dt * k, rtol=1e-6, atol=tol)
+    np.testing.assert_allclose(pos[:, 2], 50 - g * dt * dt * k * (k + 1) / 2, atol=tol * 5)
+    np.testing.assert_allclose(pos[:, :2], np.tile([1, 2], (n, 1)), atol=tol)
+    np.testing.assert_allclose(eul, 0, atol=tol)
+
+
+@pytest.mark.parametrize("prec", PREC)
+def test_hover_equilibrium(prec):
+    """Velocity set-point 0: the z-velocity integrator settles at throttle sqrt(m g / total_thrust)."""
+    cfg = O.default_config("exp03")
+    pos, vel, eul, thr = O.fly(cfg, 6, [0, 0, 0, 0], 240 * 8, [0, 0, 5], prec)
+    hover = np.sqrt(cfg.quad.mass * cfg.quad.gravity / cfg.quad.total_thrust)
+    np.testing.assert_allclose(thr[-1], hover, atol=2e-3)
+    assert abs(vel[-1, 2]) < 5e-3 and np.abs(vel[-1, :2]).max() < 1e-6 and np.abs(eul[-1]).max() < 1e-6
+    assert (thr >= 0).all() and (thr <= 1.0 + 1e-6).all()
+
+
+def test_velocity_tracking_and_axis_conventions():
+    cfg = O.default_config("exp03")
+    # +x velocity => positive pitch (nose down, z-up frame); +y => negative roll
+    pos, vel, eul, thr = O.fly(cfg, 6, [0.6, 0, 0, 0], 240 * 6, [0, 0, 5])
+    assert abs(vel[-1, 0] - 0.6) < 0.02 and abs(vel[-1, 1]) < 1e-6
+    assert eul[200:800, 1].max() > 0.02 and np.abs(eul[:, 0]).max() < 1e-9
+    pos, vel, eul, thr = O.fly(cfg, 6, [0, 0.6, 0, 0], 240 * 6, [0, 0, 5])
+    assert abs(vel[-1, 1] - 0.6) < 0.02 and eul[200:800, 0].min() < -0.02
+    pos, vel, eul, thr = O.fly(cfg, 6, [0, 0, 0, 0.5], 240 * 6, [0, 0, 5])
+    assert abs(vel[-1, 2] - 0.5) < 0.02
+    # positive yaw-rate command => positive yaw rate (mix sign and reaction-torque sign consistent)
+    pos, vel, eul, thr = O.fly(cfg, 6, [0, 0, 1.0, 0], 240 * 3, [0, 0, 5])
+    yaw = np.unwrap(eul[:, 2])
+    assert yaw[-1] > 1.0 and (np.diff(yaw[240:]) > 0).all()
+
+
+def test_mode7_position_hold():
+    """stage01 invader: mode 7 [x, y, r, z] holds its set-point (level2/components/quadcopter_manager.py:68)."""
+    cfg = O.default_config("stage01")
+    pos, vel, eul, thr = O.fly(cfg, 7, [0.5, -0.3, 0, 0.8], 240 * 12, [0.5, -0.3, 0.8])
+    assert np.abs(pos[-1] - [0.5, -0.3, 0.8]).max() < 0.05
+    pos, vel, eul, thr = O.fly(cfg, 7, [1.0, 0.0, 0, 1.0], 240 * 15, [0, 0, 1.0])
+    assert np.abs(pos[-1] - [1.0, 0.0, 1.0]).max() < 0.05
+
+
+def test_f32_build_tracks_f64():
+    cfg = O.default_config("exp03")
+    p64, v64, e64, t64 = O.fly(cfg, 6, [0.4, -0.2, 0, 0.1], 16 * 30, [0, 0, 3], "f64")
+    p32, v32, e32, t32 = O.fly(cfg, 6, [0.4, -0.2, 0, 0.1], 16 * 30, [0, 0, 3], "f32")
+    assert np.abs(p64 - p32).max() < 2e-4 and np.abs(v64 - v32).max() < 2e-4
