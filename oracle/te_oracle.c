@@ -1009,9 +1009,10 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
 
   /* (5) info, (6) observation (agent = pursuer 0) */
   int32_t inf[4] = {er->agent_kills, er->allies_kills, er->deads, er->round};
-  float* L = term && t_lidar ? t_lidar : lidar;
-  float* In = term && t_inertial ? t_inertial : inertial;
-  float* La = term && t_last_action ? t_last_action : last_action;
+  const int to_terminal = term && c->auto_reset; /* SB3: the terminal observation travels in `infos` */
+  float* L = to_terminal && t_lidar ? t_lidar : lidar;
+  float* In = to_terminal && t_inertial ? t_inertial : inertial;
+  float* La = to_terminal && t_last_action ? t_last_action : last_action;
   if (L) own_sphere(c, dr, D, 0, L);
   if (In) inertial_obs(c, &dr[0], step, max_munition_of(c, 0), In);
   if (La) for (int k = 0; k < 4; ++k) La[k] = (float)er->last_action[k];
@@ -1173,9 +1174,10 @@ static void stage02_step_env(ote_env* E, int e, const float* action, float* lida
    * compute_observation, but a drone armed after the step broadcast only has a Delta=0 snapshot and
    * the sphere reads Delta=1 (lidar_buffer.py:443-447): it is invisible this step.  Building the
    * sphere before the respawn is the same thing. */
-  float* L = term && t_lidar ? t_lidar : lidar;
-  float* In = term && t_inertial ? t_inertial : inertial;
-  float* La = term && t_last_action ? t_last_action : last_action;
+  const int to_terminal = term && c->auto_reset; /* SB3: the terminal observation travels in `infos` */
+  float* L = to_terminal && t_lidar ? t_lidar : lidar;
+  float* In = to_terminal && t_inertial ? t_inertial : inertial;
+  float* La = to_terminal && t_last_action ? t_last_action : last_action;
   if (L) own_sphere(c, dr, D, 0, L);
   if (In) inertial_obs(c, &dr[0], step, max_munition_of(c, 0), In);
   if (La) for (int k = 0; k < 4; ++k) La[k] = (float)er->last_action[k];
@@ -1276,9 +1278,10 @@ static void stage01_step_env(ote_env* E, int e, const float* action, float* lida
   note_state_margin(mg, n0, (real)c->dome_radius);
   note_state_margin(mg, n2, (real)c->dome_radius);
   int term = (er->step > er->max_step) || n0 > (real)c->dome_radius || n2 > (real)c->dome_radius;
-  L = term && t_lidar ? t_lidar : lidar;
-  In = term && t_inertial ? t_inertial : inertial;
-  La = term && t_last_action ? t_last_action : last_action;
+  const int to_terminal = term && c->auto_reset;
+  L = to_terminal && t_lidar ? t_lidar : lidar;
+  In = to_terminal && t_inertial ? t_inertial : inertial;
+  La = to_terminal && t_last_action ? t_last_action : last_action;
   if (L) own_sphere(c, dr, D, 0, L);
   if (In) inertial_obs(c, &dr[0], er->step, 0, In);
   if (La) for (int k = 0; k < 4; ++k) La[k] = (float)er->last_action[k];

@@ -1,0 +1,64 @@
+"""Helpers to read / edit the public state blob (include/threatengage.h TE_D_* / TE_E_*) in tests."""
+import numpy as np
+
+from dronechase_amd import config as K
+
+
+class Blob:
+    def __init__(self, words: np.ndarray, N: int, D: int):
+        self.w = np.array(words, dtype=np.uint32, copy=True)
+        self.N, self.D = N, D
+        self.dr = self.w[: N * D * K.DRONE_WORDS].reshape(N, D, K.DRONE_WORDS)
+        self.er = self.w[N * D * K.DRONE_WORDS:].reshape(N, K.ENV_WORDS)
+
+    # drone fields -----------------------------------------------------------------------
+    def f(self, env, d, name, n=1):
+        o = K.D[name]
+        return self.dr[env, d, o:o + n].view(np.float32)
+
+    def i(self, env, d, name):
+        return int(self.dr[env, d, K.D[name]].view(np.int32))
+
+    def set_f(self, env, d, name, vals):
+        vals = np.atleast_1d(np.asarray(vals, np.float32))
+        o = K.D[name]
+        self.dr[env, d, o:o + len(vals)] = vals.view(np.uint32)
+
+    def set_i(self, env, d, name, val):
+        self.dr[env, d, K.D[name]] = np.int32(val).view(np.uint32)
+
+    def place(self, env, d, pos, armed=1):
+        """Put drone d at rest at `pos` (world state AND last IMU read), level attitude."""
+        self.set_f(env, d, "POS", pos); self.set_f(env, d, "OBS_POS", pos); self.set_f(env, d, "FORMATION", pos)
+        self.set_f(env, d, "QUAT", [0, 0, 0, 1])
+        for name in ("VEL", "OMEGA", "OBS_EULER", "OBS_VEL", "OBS_RATE"):
+            self.set_f(env, d, name, [0, 0, 0])
+        self.set_i(env, d, "ARMED", armed)
+
+    def hover_ready(self, env, d, cfg):
+        """Pre-load throttle and the z-velocity integrator with the hover value so the drone does not sag."""
+        h = float(np.sqrt(cfg.quad.mass * cfg.quad.gravity / cfg.quad.total_thrust))
+        self.set_f(env, d, "THROTTLE", [h] * 4)
+        self.set_f(env, d, "PID_ZV_I", [h])
+
+    # env fields -------------------------------------------------------------------------
+    def ef(self, env, name, n=1):
+        o = K.E[name]
+        return self.er[env, o:o + n].view(np.float32)
+
+    def ei(self, env, name):
+        return int(self.er[env, K.E[name]].view(np.int32))
+
+    def set_ei(self, env, name, val):
+        self.er[env, K.E[name]] = np.int32(val).view(np.uint32)
+
+    def set_ef(self, env, name, vals):
+        vals = np.atleast_1d(np.asarray(vals, np.float32))
+        o = K.E[name]
+        self.er[env, o:o + len(vals)] = vals.view(np.uint32)
+
+    def armed_mask(self, env):
+        return sum((1 << d) for d in range(self.D) if self.i(env, d, "ARMED"))
+
+    def refresh_snapshot(self, env):
+        self.set_ei(env, "SNAP_MASK", self.armed_mask(env))
