@@ -21,8 +21,16 @@ enum { TE_X_CMD = TE_DRONE_WORDS, /* 3: next scripted velocity command vx,vy,vz 
        TE_X_NAV_NEXT = TE_DRONE_WORDS + 3, /* i32: FSM state after the pending update */
        TE_X_WORDS = 4 };
 
+// constants of the sub-step loop derived from te_config.  Computed ONCE on the host (te_create) and passed
+// by value in the kernel arguments, so they live in SGPRs: gfx950 has no scalar float ALU, and deriving
+// them in the kernel would pin ~20 VGPRs of wave-uniform values for the whole loop.
+struct Derived {
+  float invT, dt, k_motor, noise_ratio, q_thrust, q_arm, q_torque, k_drag, k_pqr;
+  float dt_inv_ix, dt_inv_iy, dt_inv_iz, ix, iy, iz, dt_inv_m, dt_g, pwm_floor;
+};
 struct Params {
   te_config cfg;
+  Derived kd;
   uint32_t* dstate;
   uint32_t* estate;
   int N, Npad, D;
@@ -39,6 +47,22 @@ struct Planes {
   TE_DEV int32_t& di(int w, int s) const { return reinterpret_cast<int32_t*>(d)[((size_t)w * D + s) * Npad + env]; }
   TE_DEV float& ef(int w) const { return reinterpret_cast<float*>(e)[(size_t)w * Npad + env]; }
   TE_DEV int32_t& ei(int w) const { return reinterpret_cast<int32_t*>(e)[(size_t)w * Npad + env]; }
+};
+
+// one drone slot of one env, 32-bit indexing (te_create rejects state planes beyond 2^32 bytes)
+struct SlotLane {
+  uint32_t* d; uint32_t* e; uint32_t plane_stride, off, npad, env;
+  // address = (wave-uniform plane base: SGPR pair) + (ONE shared 32-bit VGPR byte offset, zero-extended):
+  // lowers to global_load/store ... saddr with the same offset register for every plane
+  TE_DEV float& f(int w) const {
+    char* plane = reinterpret_cast<char*>(d) + (size_t)((uint32_t)w * plane_stride) * 4u;
+    return *reinterpret_cast<float*>(plane + (size_t)(uint32_t)(off << 2));
+  }
+  TE_DEV int32_t& i(int w) const { return reinterpret_cast<int32_t&>(f(w)); }
+  TE_DEV int32_t& ei(int w) const {
+    char* plane = reinterpret_cast<char*>(e) + (size_t)((uint32_t)w * npad) * 4u;
+    return *reinterpret_cast<int32_t*>(plane + (size_t)(uint32_t)(env << 2));
+  }
 };
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -67,6 +91,46 @@ TE_DEV float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16
 
 // ---------------------------------------------------------------- small math
 TE_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// gfx950 native transcendentals (1 ulp class, quarter-rate VALU) instead of the branchy libm slow paths:
+// the sub-step loop is VALU-issue-bound, so instruction count is the lever.
+TE_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }            // v_rcp_f32
+TE_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }            // v_rsq_f32
+TE_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }         // v_sqrt_f32
+TE_DEV float sin_rev(float r) { return __builtin_amdgcn_sinf(r); }        // v_sin_f32: sin(2 pi r)
+TE_DEV float cos_rev(float r) { return __builtin_amdgcn_cosf(r); }        // v_cos_f32: cos(2 pi r)
+TE_DEV float ln(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }  // v_log_f32 is log2
+// atan on [0, inf) by one reduction around tan(pi/8) + a degree-4 odd minimax (Cephes atanf), ~1e-7 abs
+TE_DEV float atan_poly(float x) {
+  float z = x * x;
+  float y = ((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f;
+  return y * z * x + x;
+}
+TE_DEV float fast_atan2(float y, float x) {
+  float ax = fabsf(x), ay = fabsf(y);
+  float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  // t = mn/mx in [0,1]; above tan(pi/8) use atan(t) = pi/4 + atan((t-1)/(t+1)) = pi/4 + atan((mn-mx)/(mn+mx))
+  bool hi = mn > 0.4142135623730950f * mx;
+  float num = hi ? mn - mx : mn, den = hi ? mn + mx : mx;
+  float t = den > 0.0f ? num * rcp(den) : 0.0f;
+  float a = atan_poly(t) + (hi ? 0.7853981633974483f : 0.0f);
+  a = ay > ax ? 1.5707963267948966f - a : a;
+  a = x < 0.0f ? kPi - a : a;
+  return copysignf(a, y);
+}
+// asin on [-1,1] (Cephes asinf), ~1e-7 abs
+TE_DEV float asin_poly(float z) {
+  return ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f);
+}
+TE_DEV float fast_asin(float x) {
+  float a = fabsf(x);
+  bool big = a > 0.5f;
+  float z = big ? 0.5f * (1.0f - a) : a * a;
+  float s = big ? fsqrt(z) : a;
+  float r = s + s * z * asin_poly(z);
+  r = big ? 1.5707963267948966f - 2.0f * r : r;
+  return copysignf(r, x);
+}
 struct V3 { float x, y, z; };
 TE_DEV float norm(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 TE_DEV V3 sub(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -76,7 +140,7 @@ struct M3 { float m00, m01, m02, m10, m11, m12, m20, m21, m22; };
 // rotation matrix of a quaternion (x,y,z,w), Bullet btMatrix3x3::setRotation form
 TE_DEV M3 rotation(Q4 q) {
   float d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-  float s = 2.0f / d;
+  float s = 2.0f * rcp(d);
   float xs = q.x * s, ys = q.y * s, zs = q.z * s;
   float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
   float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
@@ -92,14 +156,14 @@ TE_DEV V3 mulT(const M3& R, V3 v) {
             R.m02 * v.x + R.m12 * v.y + R.m22 * v.z};
 }
 // roll/pitch/yaw with pybullet's gimbal guard (getEulerFromQuaternion); R entries equal the quaternion
-// polynomials of that routine for a unit quaternion.
+// polynomials of that routine for a unit quaternion.  Polynomial atan2/asin (~1e-7): no libm in kernels.
 TE_DEV V3 euler_of(Q4 q) {
   float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, sqw = q.w * q.w;
   float sarg = -2.0f * (q.x * q.z - q.w * q.y);
-  if (sarg <= -0.99999f) return V3{0.0f, -0.5f * kPi, 2.0f * atan2f(q.x, -q.y)};
-  if (sarg >= 0.99999f) return V3{0.0f, 0.5f * kPi, 2.0f * atan2f(-q.x, q.y)};
-  return V3{atan2f(2.0f * (q.y * q.z + q.w * q.x), sqw - sqx - sqy + sqz), asinf(sarg),
-            atan2f(2.0f * (q.x * q.y + q.w * q.z), sqw + sqx - sqy - sqz)};
+  if (sarg <= -0.99999f) return V3{0.0f, -0.5f * kPi, 2.0f * fast_atan2(q.x, -q.y)};
+  if (sarg >= 0.99999f) return V3{0.0f, 0.5f * kPi, 2.0f * fast_atan2(-q.x, q.y)};
+  return V3{fast_atan2(2.0f * (q.y * q.z + q.w * q.x), sqw - sqx - sqy + sqz), fast_asin(sarg),
+            fast_atan2(2.0f * (q.x * q.y + q.w * q.z), sqw + sqx - sqy - sqz)};
 }
 // getQuaternionFromEuler (btQuaternion::setEulerZYX), normalised
 TE_DEV Q4 quat_of_euler(V3 e) {
@@ -120,10 +184,25 @@ struct Body {
   V3 o_pos, o_eul, o_vel, o_rate;
 };
 
+__host__ __device__ inline Derived derive(const te_config& c) {
+  const te_quad_params& q = c.quad;
+  Derived d;
+  d.invT = 1.0f / c.control_dt; d.dt = c.physics_dt;
+  d.k_motor = c.physics_dt / q.motor_tau; d.noise_ratio = q.noise_ratio;
+  d.q_thrust = q.total_thrust * 0.25f;                      // thrust_coef * max_rpm^2
+  d.q_arm = q.arm * d.q_thrust;
+  d.q_torque = q.torque_coef * (q.total_thrust / (4.0f * q.thrust_coef));
+  d.k_drag = 0.5f * q.air_density * q.drag_area_xyz * q.drag_coef_xyz; d.k_pqr = q.drag_coef_pqr;
+  d.ix = q.inertia[0]; d.iy = q.inertia[1]; d.iz = q.inertia[2];
+  d.dt_inv_ix = c.physics_dt / q.inertia[0]; d.dt_inv_iy = c.physics_dt / q.inertia[1]; d.dt_inv_iz = c.physics_dt / q.inertia[2];
+  d.dt_inv_m = c.physics_dt / q.mass; d.dt_g = c.physics_dt * q.gravity; d.pwm_floor = q.pwm_floor;
+  return d;
+}
+
 // PyFlyt PID.step
-TE_DEV float pid(float kp, float ki, float kd, float lim, float T, float err, float& I, float& prev) {
+TE_DEV float pid(float kp, float ki, float kd, float lim, float T, float invT, float err, float& I, float& prev) {
   I = clampf(I + ki * err * T, -lim, lim);
-  float Dv = kd * (err - prev) / T;
+  float Dv = kd * (err - prev) * invT;
   prev = err;
   return clampf(kp * err + I + Dv, -lim, lim);
 }
@@ -132,16 +211,17 @@ TE_DEV float pid(float kp, float ki, float kd, float lim, float T, float err, fl
 // integration.  Replaces quadcopter.update_imu/update_control/update_physics + stepSimulation
 // (level4_simulation.py:87-98) for one armed drone.  `sp` = [a0, a1, yaw-rate, z] set-point.
 //
-// Two algebraic identities keep the loop lean (both exact in real arithmetic):
+// Algebraic identities that keep the loop lean (exact in real arithmetic, ~1e-7 in float32):
 //  * the body components of the angular velocity are invariant under the attitude update
 //    (exp(w^ dt) w = w), so w stays in body axes for the whole loop and exp(dt w/2) is applied on the
 //    right of q;
-//  * cos/sin(yaw) come from the first column of R instead of sincos(atan2(.)).
-template <bool MODE7>
-TE_DEV void substep(const te_config& c, Body& b, const float sp[4], const float nz[4], V3& pend_f, V3& pend_t,
-                    bool last) {
+//  * cos/sin(yaw) come from the first column of R instead of sincos(atan2(.));
+//  * sin/cos of the half rotation angle (< 0.5 rad per 1/240 s for any sane rate) by Taylor polynomials.
+template <bool MODE7, bool CAPTURE>
+TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float sp[4], const float nz[4], V3& pend_f,
+                    V3& pend_t) {
   const te_quad_params& qp = c.quad;
-  const float T = c.control_dt, dt = c.physics_dt;
+  const float T = c.control_dt, dt = k.dt;
   M3 R = rotation(b.q);
   // ---- IMU (imu.py:27-41)
   V3 vb = mulT(R, b.vel);
@@ -149,17 +229,20 @@ TE_DEV void substep(const te_config& c, Body& b, const float sp[4], const float 
   float roll, pitch, cyaw, syaw;
   bool guard = fabsf(sarg) >= 0.99999f;
   if (!guard) {
-    roll = atan2f(R.m21, R.m22);
-    pitch = asinf(sarg);
-    float inv = 1.0f / sqrtf(R.m00 * R.m00 + R.m10 * R.m10);
+    roll = fast_atan2(R.m21, R.m22);
+    pitch = fast_asin(sarg);
+    float inv = rsq(R.m00 * R.m00 + R.m10 * R.m10);
     cyaw = R.m00 * inv; syaw = R.m10 * inv;
-  } else {
-    V3 e = euler_of(b.q);
-    roll = e.x; pitch = e.y; sincosf(e.z, &syaw, &cyaw);
+  } else {  // pybullet's gimbal guard (rare): roll = 0, pitch = +-pi/2, yaw = 2 atan2(+-x, -+y)
+    roll = 0.0f; pitch = sarg > 0.0f ? 0.5f * kPi : -0.5f * kPi;
+    float sy = sarg > 0.0f ? -b.q.x : b.q.x, cy = sarg > 0.0f ? b.q.y : -b.q.y;  // half-angle direction
+    float inv = rsq(fmaxf(sy * sy + cy * cy, 1e-30f));
+    sy *= inv; cy *= inv;
+    cyaw = cy * cy - sy * sy; syaw = 2.0f * sy * cy;  // double angle
   }
-  if (last) {
+  if (CAPTURE) {  // the IMU read the observation / reward / engagement will see (one-sub-step lag)
     b.o_pos = b.pos; b.o_vel = vb; b.o_rate = b.wb;
-    b.o_eul = guard ? euler_of(b.q) : V3{roll, pitch, atan2f(R.m10, R.m00)};
+    b.o_eul = guard ? euler_of(b.q) : V3{roll, pitch, fast_atan2(R.m10, R.m00)};
   }
   // ---- controller (PyFlyt QuadX.update_control; every sub-step, PID period control_dt)
   float a0 = sp[0], a1 = sp[1], zc = sp[3];
@@ -169,47 +252,45 @@ TE_DEV void substep(const te_config& c, Body& b, const float sp[4], const float 
     zc = clampf(qp.z_pos_kp * (zc - b.pos.z), -qp.z_pos_lim, qp.z_pos_lim);
   }
   float u = cyaw * a0 + syaw * a1, v = -syaw * a0 + cyaw * a1;
-  float ox = pid(qp.lin_vel_kp[0], qp.lin_vel_ki[0], qp.lin_vel_kd[0], qp.lin_vel_lim[0], T, u - vb.x, b.lv_i[0], b.lv_e[0]);
-  float oy = pid(qp.lin_vel_kp[1], qp.lin_vel_ki[1], qp.lin_vel_kd[1], qp.lin_vel_lim[1], T, v - vb.y, b.lv_i[1], b.lv_e[1]);
+  float ox = pid(qp.lin_vel_kp[0], qp.lin_vel_ki[0], qp.lin_vel_kd[0], qp.lin_vel_lim[0], T, k.invT, u - vb.x, b.lv_i[0], b.lv_e[0]);
+  float oy = pid(qp.lin_vel_kp[1], qp.lin_vel_ki[1], qp.lin_vel_kd[1], qp.lin_vel_lim[1], T, k.invT, v - vb.y, b.lv_i[1], b.lv_e[1]);
   float r0 = clampf(qp.ang_pos_kp[0] * (-oy - roll), -qp.ang_pos_lim[0], qp.ang_pos_lim[0]);
   float r1 = clampf(qp.ang_pos_kp[1] * (ox - pitch), -qp.ang_pos_lim[1], qp.ang_pos_lim[1]);
-  float t0 = pid(qp.ang_vel_kp[0], qp.ang_vel_ki[0], qp.ang_vel_kd[0], qp.ang_vel_lim[0], T, r0 - b.wb.x, b.av_i[0], b.av_e[0]);
-  float t1 = pid(qp.ang_vel_kp[1], qp.ang_vel_ki[1], qp.ang_vel_kd[1], qp.ang_vel_lim[1], T, r1 - b.wb.y, b.av_i[1], b.av_e[1]);
-  float t2 = pid(qp.ang_vel_kp[2], qp.ang_vel_ki[2], qp.ang_vel_kd[2], qp.ang_vel_lim[2], T, sp[2] - b.wb.z, b.av_i[2], b.av_e[2]);
-  float th = pid(qp.z_vel_kp, qp.z_vel_ki, qp.z_vel_kd, qp.z_vel_lim, T, zc - vb.z, b.zv_i, b.zv_e);
+  float t0 = pid(qp.ang_vel_kp[0], qp.ang_vel_ki[0], qp.ang_vel_kd[0], qp.ang_vel_lim[0], T, k.invT, r0 - b.wb.x, b.av_i[0], b.av_e[0]);
+  float t1 = pid(qp.ang_vel_kp[1], qp.ang_vel_ki[1], qp.ang_vel_kd[1], qp.ang_vel_lim[1], T, k.invT, r1 - b.wb.y, b.av_i[1], b.av_e[1]);
+  float t2 = pid(qp.ang_vel_kp[2], qp.ang_vel_ki[2], qp.ang_vel_kd[2], qp.ang_vel_lim[2], T, k.invT, sp[2] - b.wb.z, b.av_i[2], b.av_e[2]);
+  float th = pid(qp.z_vel_kp, qp.z_vel_ki, qp.z_vel_kd, qp.z_vel_lim, T, k.invT, zc - vb.z, b.zv_i, b.zv_e);
   th = clampf(th, 0.0f, 1.0f);
   float pwm[4] = {-t0 - t1 + t2 + th, t0 + t1 + t2 + th, -t0 + t1 - t2 + th, t0 - t1 - t2 + th};
   float hi = fmaxf(fmaxf(pwm[0], pwm[1]), fmaxf(pwm[2], pwm[3]));
   if (hi > 1.0f) {
+    float s = rcp(hi);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pwm[i] /= hi;
+    for (int i = 0; i < 4; ++i) pwm[i] *= s;
   }
   float lo = fminf(fminf(pwm[0], pwm[1]), fminf(pwm[2], pwm[3]));
-  if (lo < qp.pwm_floor) {
+  if (lo < k.pwm_floor) {
+    float f = (k.pwm_floor - lo) * rcp(1.0f - lo);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pwm[i] += (1.0f - pwm[i]) / (1.0f - lo) * (qp.pwm_floor - lo);
+    for (int i = 0; i < 4; ++i) pwm[i] += (1.0f - pwm[i]) * f;
   }
   // ---- motors (first-order lag, multiplicative noise, thrust/torque ~ rpm^2) + drag
-  const float k = dt / qp.motor_tau;
-  const float max_rpm2 = qp.total_thrust / (4.0f * qp.thrust_coef);
   float T_[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float t = b.thr[i];
-    t += k * (pwm[i] - t);
-    t += nz[i] * t * qp.noise_ratio;
+    t += k.k_motor * (pwm[i] - t);
+    t += nz[i] * t * k.noise_ratio;
     b.thr[i] = t;
-    T_[i] = t * t * max_rpm2;
+    T_[i] = t * t;
   }
   // layout m0 front-right (+x,-y), m1 back-left (-x,+y), m2 back-right (-x,-y), m3 front-left (+x,+y)
-  float fz = qp.thrust_coef * (T_[0] + T_[1] + T_[2] + T_[3]);
-  float tx = qp.arm * qp.thrust_coef * (-T_[0] + T_[1] - T_[2] + T_[3]);
-  float ty = qp.arm * qp.thrust_coef * (-T_[0] + T_[1] + T_[2] - T_[3]);
-  float tz = qp.torque_coef * (T_[0] + T_[1] - T_[2] - T_[3]);
-  const float kd = 0.5f * qp.air_density * qp.drag_area_xyz * qp.drag_coef_xyz;
-  V3 Fb{-kd * fabsf(vb.x) * vb.x, -kd * fabsf(vb.y) * vb.y, -kd * fabsf(vb.z) * vb.z + fz};
-  V3 Tb{tx - qp.drag_coef_pqr * fabsf(b.wb.x) * b.wb.x, ty - qp.drag_coef_pqr * fabsf(b.wb.y) * b.wb.y,
-        tz - qp.drag_coef_pqr * fabsf(b.wb.z) * b.wb.z};
+  float fz = k.q_thrust * (T_[0] + T_[1] + T_[2] + T_[3]);
+  float tx = k.q_arm * (-T_[0] + T_[1] - T_[2] + T_[3]);
+  float ty = k.q_arm * (-T_[0] + T_[1] + T_[2] - T_[3]);
+  float tz = k.q_torque * (T_[0] + T_[1] - T_[2] - T_[3]);
+  V3 Fb{-k.k_drag * fabsf(vb.x) * vb.x, -k.k_drag * fabsf(vb.y) * vb.y, -k.k_drag * fabsf(vb.z) * vb.z + fz};
+  V3 Tb{tx - k.k_pqr * fabsf(b.wb.x) * b.wb.x, ty - k.k_pqr * fabsf(b.wb.y) * b.wb.y, tz - k.k_pqr * fabsf(b.wb.z) * b.wb.z};
   V3 Fw = mul(R, Fb);
   if (MODE7) {  // wrench accumulated outside the loop (stage01 replace_invader), world frame
     Fw.x += pend_f.x; Fw.y += pend_f.y; Fw.z += pend_f.z;
@@ -218,33 +299,36 @@ TE_DEV void substep(const te_config& c, Body& b, const float sp[4], const float 
     pend_f = V3{0, 0, 0}; pend_t = V3{0, 0, 0};
   }
   // ---- Bullet semi-implicit Euler (stepSimulation): gyroscopic term, exponential-map attitude update
-  float Ix = qp.inertia[0], Iy = qp.inertia[1], Iz = qp.inertia[2];
-  V3 Iw{Ix * b.wb.x, Iy * b.wb.y, Iz * b.wb.z};
+  V3 Iw{k.ix * b.wb.x, k.iy * b.wb.y, k.iz * b.wb.z};
   V3 gy{b.wb.y * Iw.z - b.wb.z * Iw.y, b.wb.z * Iw.x - b.wb.x * Iw.z, b.wb.x * Iw.y - b.wb.y * Iw.x};
-  b.wb = V3{b.wb.x + dt * (Tb.x - gy.x) / Ix, b.wb.y + dt * (Tb.y - gy.y) / Iy, b.wb.z + dt * (Tb.z - gy.z) / Iz};
-  float inv_m = 1.0f / qp.mass;
-  b.vel = V3{b.vel.x + dt * Fw.x * inv_m, b.vel.y + dt * Fw.y * inv_m, b.vel.z + dt * (Fw.z * inv_m - qp.gravity)};
+  b.wb = V3{b.wb.x + k.dt_inv_ix * (Tb.x - gy.x), b.wb.y + k.dt_inv_iy * (Tb.y - gy.y), b.wb.z + k.dt_inv_iz * (Tb.z - gy.z)};
+  b.vel = V3{b.vel.x + k.dt_inv_m * Fw.x, b.vel.y + k.dt_inv_m * Fw.y, b.vel.z + (k.dt_inv_m * Fw.z - k.dt_g)};
   b.pos = V3{b.pos.x + dt * b.vel.x, b.pos.y + dt * b.vel.y, b.pos.z + dt * b.vel.z};
-  float wmag = norm(b.wb);
-  float half = 0.5f * wmag * dt;
-  float sc, ch;
-  if (wmag < 1e-6f) { sc = 0.5f * dt * (1.0f - half * half / 6.0f); ch = cosf(half); }
-  else { float sh; sincosf(half, &sh, &ch); sc = sh / wmag; }
+  float w2 = b.wb.x * b.wb.x + b.wb.y * b.wb.y + b.wb.z * b.wb.z;
+  float h2 = 0.25f * dt * dt * w2;  // (half angle)^2
+  float sc, ch;                     // sin(h)/|w| and cos(h)
+  if (h2 < 0.25f) {
+    sc = 0.5f * dt * (1.0f + h2 * (-1.0f / 6.0f + h2 * (1.0f / 120.0f + h2 * (-1.0f / 5040.0f + h2 * (1.0f / 362880.0f)))));
+    ch = 1.0f + h2 * (-0.5f + h2 * (1.0f / 24.0f + h2 * (-1.0f / 720.0f + h2 * (1.0f / 40320.0f + h2 * (-1.0f / 3628800.0f)))));
+  } else {  // > 240 rad/s: native sin/cos (inputs in revolutions) are plenty
+    float inv_w = rsq(w2);
+    float rev = 0.5f * dt * (w2 * inv_w) * (0.5f / kPi);
+    sc = sin_rev(rev) * inv_w; ch = cos_rev(rev);
+  }
   Q4 dq{b.wb.x * sc, b.wb.y * sc, b.wb.z * sc, ch};
   Q4 q = b.q;  // q <- q (x) dq   (body-frame increment on the right)
   Q4 n{q.w * dq.x + q.x * dq.w + q.y * dq.z - q.z * dq.y, q.w * dq.y - q.x * dq.z + q.y * dq.w + q.z * dq.x,
        q.w * dq.z + q.x * dq.y - q.y * dq.x + q.z * dq.w, q.w * dq.w - q.x * dq.x - q.y * dq.y - q.z * dq.z};
-  float inv = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w);
+  float inv = rsq(n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w);
   b.q = Q4{n.x * inv, n.y * inv, n.z * inv, n.w * inv};
 }
 
+// 4 standard normals per (env, slot, step, sub-step): Philox4x32-10 + Box-Muller on native log/sin/cos
 TE_DEV void motor_noise(const te_config& c, int env, int slot, uint32_t episode, uint32_t step_index, int sub, float nz[4]) {
   U4 r = env_rng(c, env, RNG_MOTOR, (uint32_t)slot, (uint32_t)sub, episode, step_index);
-  float r0 = sqrtf(-2.0f * logf(u01_open(r.x))), r1 = sqrtf(-2.0f * logf(u01_open(r.z)));
-  float s0, c0, s1, c1;
-  sincosf(2.0f * kPi * u01(r.y), &s0, &c0);
-  sincosf(2.0f * kPi * u01(r.w), &s1, &c1);
-  nz[0] = r0 * c0; nz[1] = r0 * s0; nz[2] = r1 * c1; nz[3] = r1 * s1;
+  float r0 = fsqrt(-2.0f * ln(u01_open(r.x))), r1 = fsqrt(-2.0f * ln(u01_open(r.z)));
+  float a0 = u01(r.y), a1 = u01(r.w);  // revolutions
+  nz[0] = r0 * cos_rev(a0); nz[1] = r0 * sin_rev(a0); nz[2] = r1 * cos_rev(a1); nz[3] = r1 * sin_rev(a1);
 }
 
 // Quadcopter.convert_command_to_setpoint (quadcopter.py:379-396): unit(direction) * magnitude
