@@ -323,12 +323,21 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
   b.q = Q4{n.x * inv, n.y * inv, n.z * inv, n.w * inv};
 }
 
-// 4 standard normals per (env, slot, step, sub-step): Philox4x32-10 + Box-Muller on native log/sin/cos
-TE_DEV void motor_noise(const te_config& c, int env, int slot, uint32_t episode, uint32_t step_index, int sub, float nz[4]) {
-  U4 r = env_rng(c, env, RNG_MOTOR, (uint32_t)slot, (uint32_t)sub, episode, step_index);
-  float r0 = fsqrt(-2.0f * ln(u01_open(r.x))), r1 = fsqrt(-2.0f * ln(u01_open(r.z)));
-  float a0 = u01(r.y), a1 = u01(r.w);  // revolutions
+// Motor noise: 4 standard normals per sub-step.  One Philox4x32-10 call (40 quarter-rate integer multiplies)
+// serves TWO consecutive sub-steps: 128 bits = eight 16-bit uniforms = four Box-Muller pairs on the native
+// log / sqrt / sin / cos.  Sub-step `sub` uses words {x,y} when even, {z,w} when odd, of call index sub >> 1.
+TE_DEV U4 motor_noise_bits(const te_config& c, int env, int slot, uint32_t episode, uint32_t step_index, int sub) {
+  return env_rng(c, env, RNG_MOTOR, (uint32_t)slot, (uint32_t)(sub >> 1), episode, step_index);
+}
+TE_DEV void motor_noise_from(const U4& r, int sub, float nz[4]) {
+  const uint32_t a = (sub & 1) ? r.z : r.x, b = (sub & 1) ? r.w : r.y;
+  const float k16 = 1.0f / 65536.0f;
+  float r0 = fsqrt(-2.0f * ln(((float)(a & 0xFFFFu) + 0.5f) * k16)), r1 = fsqrt(-2.0f * ln(((float)(b & 0xFFFFu) + 0.5f) * k16));
+  float a0 = (float)(a >> 16) * k16, a1 = (float)(b >> 16) * k16;  // revolutions
   nz[0] = r0 * cos_rev(a0); nz[1] = r0 * sin_rev(a0); nz[2] = r1 * cos_rev(a1); nz[3] = r1 * sin_rev(a1);
+}
+TE_DEV void motor_noise(const te_config& c, int env, int slot, uint32_t episode, uint32_t step_index, int sub, float nz[4]) {
+  motor_noise_from(motor_noise_bits(c, env, slot, episode, step_index, sub), sub, nz);
 }
 
 // Quadcopter.convert_command_to_setpoint (quadcopter.py:379-396): unit(direction) * magnitude

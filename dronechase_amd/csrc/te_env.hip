@@ -38,66 +38,106 @@ namespace te {
 #else
 #define TE_K1_ATTR
 #endif
-template <int FAMILY, bool NOISE>
-__global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params p, const float* __restrict__ actions) {
+// LIDAR background (LIDARSpec.empty_sphere, angle_grid.py:95-104: all ones) streamed by the sub-step
+// kernel's waves: each wave owns kFillQuads * 64 float4 of the [N,3,13,26] buffer.  The stores are issued
+// right after the armed flag is requested and drain while the wave flies its 16 sub-steps (or retires, for
+// a disarmed slot), so the 4 KB/env observation write rides on the latency-bound physics for free.
+struct FillJob { float* lidar; uint32_t total_quads; };
+
+// KFILL = float4 stores per lane (0 = no fill in this launch).  It is a template constant so the wait
+// for the armed flag can be a counted s_waitcnt vmcnt(KFILL): on gfx950 loads and stores retire through one
+// in-order counter, and a run-time store count would force vmcnt(0), i.e. every wave would first wait for
+// its 6 KB of background stores to be acknowledged.
+template <int FAMILY, bool NOISE, int KFILL>
+__global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params p, const float* __restrict__ actions, FillJob fill) {
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (unsigned)TE_K1_BLOCK + threadIdx.x) >> 6));
   const int lane = threadIdx.x & 63;
   const int D = p.D;
   const int chunk = wave / D;
   const int slot = wave - chunk * D;
   if (chunk >= (p.Npad >> 6)) return;
-  const int env = chunk * 64 + lane;
-  if (env >= p.N) return;
+  const int env = chunk * 64 + lane;  // planes are padded to Npad: lanes beyond N still read in bounds
   // 32-bit element index = plane * (D * Npad) + (slot * Npad + env): the plane term is wave-uniform (SGPR),
   // so every access is "scalar base + one shared VGPR offset" and no 64-bit address pairs stay live
   const SlotLane P{p.dstate, p.estate, (uint32_t)D * (uint32_t)p.Npad, (uint32_t)slot * (uint32_t)p.Npad + (uint32_t)env,
                    (uint32_t)p.Npad, (uint32_t)env};
-  if (!P.i(TE_D_ARMED)) return;
+  const int armed = P.i(TE_D_ARMED);
+  const bool active = env < p.N && armed != 0;
   const te_config& c = p.cfg;
+  const bool mode7 = (FAMILY == FAM_STAGE01) && slot == 2;
+
+  // ---- every load of an armed lane is ISSUED before the background stores (in-order vmcnt: a load issued
+  // after them could only be waited for together with them)
+  float4 act = make_float4(0, 0, 0, 0);
+  float cmd[4] = {0, 0, 0, 0};
+  int nav_next = 0;
+  float raw[29];
+#pragma unroll
+  for (int k = 0; k < 29; ++k) raw[k] = 0.0f;
+  V3 pf{0, 0, 0}, pt{0, 0, 0};
+  uint32_t episode = 0, step_index = 0;
+  if (active) {
+    if (slot == 0) act = reinterpret_cast<const float4*>(actions)[env];
+    else if (FAMILY == FAM_LEVEL4) {  // scripted drones: command prepared by the previous K2 / reset
+      cmd[0] = P.f(TE_X_CMD + 0); cmd[1] = P.f(TE_X_CMD + 1); cmd[3] = P.f(TE_X_CMD + 2);
+      if (slot >= c.n_pursuers) nav_next = P.i(TE_X_NAV_NEXT);
+    } else {                          // stage01 / stage02: persistent set-points
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cmd[k] = P.f(TE_D_SETPOINT + k);
+    }
+#pragma unroll
+    for (int k = 0; k < 29; ++k) raw[k] = P.f(TE_D_POS + k);  // POS .. PID_ZV_E are words 0..28
+    if (mode7) {
+      pf = V3{P.f(TE_D_PENDING), P.f(TE_D_PENDING + 1), P.f(TE_D_PENDING + 2)};
+      pt = V3{P.f(TE_D_PENDING + 3), P.f(TE_D_PENDING + 4), P.f(TE_D_PENDING + 5)};
+    }
+    episode = (uint32_t)P.ei(TE_E_EPISODE);
+    // stage01 counts step_calls BEFORE the sim loop (pyflyt_level2_environment_modified_v2.py:128)
+    step_index = (uint32_t)P.ei(TE_E_STEP) + (FAMILY == FAM_STAGE01 ? 1u : 0u);
+  }
+  // LIDAR background stores.  ONE store per lane goes here, between the load block and the divergent early
+  // exit: with hipcc (ROCm 7.2) that keeps the two regions apart and the kernel allocates 96 VGPRs
+  // (5 waves/SIMD, no spills) instead of 134 (3 waves/SIMD).  The other KFILL-1 are issued LAST by an armed
+  // lane, so they drain behind its own critical path (loads -> 16 sub-steps -> state stores), and right
+  // away by a lane that has no drone to fly.
+  constexpr int KFIRST = KFILL < 1 ? KFILL : 1;
+  const float4 ones = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+  float4* fill_dst = reinterpret_cast<float4*>(fill.lidar);
+  const uint32_t fill_q0 = (uint32_t)wave * (uint32_t)(KFILL * 64) + (uint32_t)lane, fill_last = fill.total_quads - 1u;
+#pragma unroll
+  for (int k = 0; k < KFIRST; ++k) fill_dst[min(fill_q0 + (uint32_t)(k * 64), fill_last)] = ones;  // clamped, never predicated
+  auto background = [&]() {
+#pragma unroll
+    for (int k = KFIRST; k < KFILL; ++k) fill_dst[min(fill_q0 + (uint32_t)(k * 64), fill_last)] = ones;
+  };
+  if (!active) { background(); return; }
 
   // ---- set-point for this env.step
   float sp[4];
   if (slot == 0) {  // RL agent: Quadcopter.drive (quadcopter.py:398-413)
-    const float4 a = reinterpret_cast<const float4*>(actions)[env];
-    command_to_velocity(a.x, a.y, a.z, a.w, sp[0], sp[1], sp[3]);
+    command_to_velocity(act.x, act.y, act.z, act.w, sp[0], sp[1], sp[3]);
     sp[2] = 0.0f;
-  } else if (FAMILY == FAM_LEVEL4) {  // scripted drones: command prepared by the previous K2 / reset
-    sp[0] = P.f(TE_X_CMD + 0); sp[1] = P.f(TE_X_CMD + 1); sp[2] = 0.0f; sp[3] = P.f(TE_X_CMD + 2);
-    if (slot >= c.n_pursuers) P.i(TE_D_NAV_STATE) = P.i(TE_X_NAV_NEXT);
-  } else {  // stage01 / stage02: persistent set-points
+  } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sp[k] = P.f(TE_D_SETPOINT + k);
+    for (int k = 0; k < 4; ++k) sp[k] = cmd[k];
+    if (FAMILY == FAM_LEVEL4 && slot >= c.n_pursuers) P.i(TE_D_NAV_STATE) = nav_next;
   }
   if (slot == 0 || FAMILY == FAM_LEVEL4) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) P.f(TE_D_SETPOINT + k) = sp[k];
   }
-
-  // ---- load
   Body b;
-  b.pos = V3{P.f(TE_D_POS), P.f(TE_D_POS + 1), P.f(TE_D_POS + 2)};
-  b.q = Q4{P.f(TE_D_QUAT), P.f(TE_D_QUAT + 1), P.f(TE_D_QUAT + 2), P.f(TE_D_QUAT + 3)};
-  b.vel = V3{P.f(TE_D_VEL), P.f(TE_D_VEL + 1), P.f(TE_D_VEL + 2)};
-  {
-    V3 ww{P.f(TE_D_OMEGA), P.f(TE_D_OMEGA + 1), P.f(TE_D_OMEGA + 2)};
-    b.wb = mulT(rotation(b.q), ww);
-  }
+  b.pos = V3{raw[TE_D_POS], raw[TE_D_POS + 1], raw[TE_D_POS + 2]};
+  b.q = Q4{raw[TE_D_QUAT], raw[TE_D_QUAT + 1], raw[TE_D_QUAT + 2], raw[TE_D_QUAT + 3]};
+  b.vel = V3{raw[TE_D_VEL], raw[TE_D_VEL + 1], raw[TE_D_VEL + 2]};
+  b.wb = mulT(rotation(b.q), V3{raw[TE_D_OMEGA], raw[TE_D_OMEGA + 1], raw[TE_D_OMEGA + 2]});
 #pragma unroll
-  for (int k = 0; k < 4; ++k) b.thr[k] = P.f(TE_D_THROTTLE + k);
+  for (int k = 0; k < 4; ++k) b.thr[k] = raw[TE_D_THROTTLE + k];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { b.av_i[k] = P.f(TE_D_PID_AV_I + k); b.av_e[k] = P.f(TE_D_PID_AV_E + k); }
+  for (int k = 0; k < 3; ++k) { b.av_i[k] = raw[TE_D_PID_AV_I + k]; b.av_e[k] = raw[TE_D_PID_AV_E + k]; }
 #pragma unroll
-  for (int k = 0; k < 2; ++k) { b.lv_i[k] = P.f(TE_D_PID_LV_I + k); b.lv_e[k] = P.f(TE_D_PID_LV_E + k); }
-  b.zv_i = P.f(TE_D_PID_ZV_I); b.zv_e = P.f(TE_D_PID_ZV_E);
-  V3 pf{0, 0, 0}, pt{0, 0, 0};
-  const bool mode7 = (FAMILY == FAM_STAGE01) && slot == 2;
-  if (mode7) {
-    pf = V3{P.f(TE_D_PENDING), P.f(TE_D_PENDING + 1), P.f(TE_D_PENDING + 2)};
-    pt = V3{P.f(TE_D_PENDING + 3), P.f(TE_D_PENDING + 4), P.f(TE_D_PENDING + 5)};
-  }
-  const uint32_t episode = (uint32_t)P.ei(TE_E_EPISODE);
-  // stage01 counts step_calls BEFORE the sim loop (pyflyt_level2_environment_modified_v2.py:128)
-  const uint32_t step_index = (uint32_t)P.ei(TE_E_STEP) + (FAMILY == FAM_STAGE01 ? 1u : 0u);
+  for (int k = 0; k < 2; ++k) { b.lv_i[k] = raw[TE_D_PID_LV_I + k]; b.lv_e[k] = raw[TE_D_PID_LV_E + k]; }
+  b.zv_i = raw[TE_D_PID_ZV_I]; b.zv_e = raw[TE_D_PID_ZV_E];
 
   // ---- fly.  The sub-step that captures the lagged IMU read is peeled out of the loop so the 12 observation
   // registers are not live (and conditionally written) across it.
@@ -105,13 +145,20 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   const Derived& kd = p.kd;
   float nz[4] = {0, 0, 0, 0};
   const int n_plain = c.observe_lag ? S - 1 : S;
+  U4 bits{0, 0, 0, 0};
   for (int s = 0; s < n_plain; ++s) {
-    if (NOISE) motor_noise(c, env, slot, episode, step_index, s, nz);
+    if (NOISE) {
+      if ((s & 1) == 0) bits = motor_noise_bits(c, env, slot, episode, step_index, s);  // one Philox per two sub-steps
+      motor_noise_from(bits, s, nz);
+    }
     if (mode7) substep<true, false>(c, kd, b, sp, nz, pf, pt);  // wave-uniform: slot is per wave
     else substep<false, false>(c, kd, b, sp, nz, pf, pt);
   }
   if (c.observe_lag) {
-    if (NOISE) motor_noise(c, env, slot, episode, step_index, S - 1, nz);
+    if (NOISE) {
+      if (((S - 1) & 1) == 0) bits = motor_noise_bits(c, env, slot, episode, step_index, S - 1);
+      motor_noise_from(bits, S - 1, nz);
+    }
     if (mode7) substep<true, true>(c, kd, b, sp, nz, pf, pt);
     else substep<false, true>(c, kd, b, sp, nz, pf, pt);
   }
@@ -141,6 +188,7 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
 #pragma unroll
     for (int k = 0; k < 6; ++k) P.f(TE_D_PENDING + k) = 0.0f;
   }
+  background();
 }
 
 // ============================================================================================
@@ -202,8 +250,8 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
   const Rows r{p.D, p.cfg.n_pursuers};
   const int env0 = blockIdx.x * kEPB;
   const int nvalid = min(kEPB, p.N - env0);
-  // The [N,3,13,26] LIDAR buffer has already been filled with ones by fill_ones_kernel on the side stream
-  // (overlapped with the sub-step kernel, joined before this launch): only the hit cells are patched here.
+  // The [N,3,13,26] LIDAR buffer has already been filled with ones by the sub-step kernel's waves
+  // (FillJob): only the hit cells are patched here.
   stage_block(p, sm, r, env0);
 #if defined(TE_K2_STOP) && TE_K2_STOP == 1
   if (sm[threadIdx.x] == 0x12345u) o.reward[0] = 1.0f; return;
@@ -325,8 +373,6 @@ struct te_env {
   int device;
   int family;
   size_t lds_bytes;
-  hipStream_t side = nullptr;        // LIDAR background fill, overlapped with the sub-step kernel
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // profiling (te_profile_begin / te_profile_end)
   std::vector<hipEvent_t> events;
   int prof_cap = 0, prof_used = 0;
@@ -405,13 +451,6 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     delete e;
     return fail("te_create: hipMalloc failed");
   }
-  if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
-    (void)hipFree(e->p.dstate); (void)hipFree(e->p.estate);
-    delete e;
-    return fail("te_create: could not create the side stream / events");
-  }
   TE_HIP(hipMemsetAsync(e->p.dstate, 0, dwords * 4, nullptr));
   TE_HIP(hipMemsetAsync(e->p.estate, 0, ewords * 4, nullptr));
   hipLaunchKernelGGL(init_planes, dim3(256), dim3(256), 0, nullptr, e->p);
@@ -429,9 +468,6 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   if (!e) return;
   DeviceGuard guard(e->device);
   for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
-  if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   (void)hipFree(e->p.dstate);
   (void)hipFree(e->p.estate);
   delete e;
@@ -473,24 +509,44 @@ __attribute__((visibility("default"))) int te_step(te_env* e, const float* actio
   const Params& p = e->p;
   const bool prof = e->prof_used + 3 <= e->prof_cap;
   if (prof) TE_HIP(hipEventRecord(e->events[e->prof_used + 0], st));
-  if (obs_lidar) {  // fork: ones background on the side stream, after everything already queued on `st`
-    TE_HIP(hipEventRecord(e->ev_fork, st));
-    TE_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-    const size_t n_floats = (size_t)p.N * TE_OBS_LIDAR_WORDS;
-    hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, e->side, obs_lidar, n_floats);
-    TE_HIP(hipEventRecord(e->ev_join, e->side));
-  }
   const int waves = p.D * (p.Npad >> 6);
   constexpr int wpb = TE_K1_BLOCK / 64;
   const int b1 = (waves + wpb - 1) / wpb;
   const bool noise = p.cfg.motor_noise != 0;
+  // LIDAR background: N*1014 floats = quads float4 (+ <4 tail floats).  Each wave streams KFILL*64 float4.
+  FillJob fill{nullptr, 0u};
+  int kfill = 0;
+  const size_t n_floats = (size_t)p.N * TE_OBS_LIDAR_WORDS;
+  if (obs_lidar) {
+    const size_t quads = n_floats >> 2;
+    const size_t need = (quads + (size_t)waves * 64 - 1) / ((size_t)waves * 64);  // float4 per lane
+    for (int k : {24, 26, 37}) if (kfill == 0 && need <= (size_t)k) kfill = k;
+    if (kfill && quads < (1ull << 32) && quads > 0) {
+      fill = FillJob{obs_lidar, (uint32_t)quads};
+#ifdef TE_DEBUG_FILL_CLAMP
+      fill.total_quads = 1u;  // experiment: every background store hits one quad (no HBM stream)
+#endif
+      if (n_floats & 3) hipLaunchKernelGGL(fill_ones_kernel, dim3(1), dim3(64), 0, st, obs_lidar + (quads << 2), n_floats & 3);
+    } else {  // shapes the in-kernel fill does not cover (e.g. 3 drones per env): plain fill kernel first
+      kfill = 0;
+      hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, obs_lidar, n_floats);
+    }
+  }
   launch_by_family(e->family, [&](auto fam) {
     constexpr int F = decltype(fam)::value;
-    if (noise) hipLaunchKernelGGL((substeps_kernel<F, true>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p, actions);
-    else hipLaunchKernelGGL((substeps_kernel<F, false>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p, actions);
+    auto go = [&](auto kf) {
+      constexpr int K = decltype(kf)::value;
+      if (noise) hipLaunchKernelGGL((substeps_kernel<F, true, K>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p, actions, fill);
+      else hipLaunchKernelGGL((substeps_kernel<F, false, K>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p, actions, fill);
+    };
+    switch (kfill) {
+      case 24: go(std::integral_constant<int, 24>{}); break;
+      case 26: go(std::integral_constant<int, 26>{}); break;
+      case 37: go(std::integral_constant<int, 37>{}); break;
+      default: go(std::integral_constant<int, 0>{}); break;
+    }
   });
   if (prof) TE_HIP(hipEventRecord(e->events[e->prof_used + 1], st));
-  if (obs_lidar) TE_HIP(hipStreamWaitEvent(st, e->ev_join, 0));  // join before the hit cells are patched
   const int b2 = (p.N + kEPB - 1) / kEPB;
   StepOut o{reward, done, info, ObsOut{obs_lidar, obs_inertial, obs_last_action},
             ObsOut{terminal_lidar, terminal_inertial, terminal_last_action}};

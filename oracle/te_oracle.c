@@ -103,8 +103,8 @@ OTE_API void ote_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_
 
 /* uniform in [0,1): 24 high bits, exact in float and double */
 static real u01(uint32_t x) { return (real)(x >> 8) * (real)(1.0 / 16777216.0); }
-/* uniform in (0,1): for log() */
-static real u01_open(uint32_t x) { return ((real)(x >> 8) + (real)0.5) * (real)(1.0 / 16777216.0); }
+
+
 
 /* counter = { global env (low 32), purpose | slot<<8 | sub<<16 | global env (high 8)<<24, episode, index } */
 static void ote_rng(const ote_env* E, int env_local, uint32_t purpose, uint32_t slot, uint32_t sub, uint32_t episode,
@@ -347,13 +347,18 @@ static void integrate(const te_config* c, ote_drone* d, const real Fw[3], const 
   d->quat[0] = x / n; d->quat[1] = y / n; d->quat[2] = z / n; d->quat[3] = w / n;
 }
 
+/* Motors.physics_update noise: 4 standard normals per (env, slot, step, sub-step).  One Philox4x32-10 call
+ * serves TWO consecutive sub-steps: its 128 bits are split into eight 16-bit uniforms = four Box-Muller
+ * pairs (the reference draws np_random.randn(4) from an unseeded stream, quadcopter.py:137,181; any N(0,1)
+ * source restates it).  Sub-step `sub` uses words {0,1} when even, {2,3} when odd, of call index sub >> 1. */
 static void motor_noise(const ote_env* E, int e, int slot, uint32_t step_index, int sub, real out[4]) {
   if (!E->cfg.motor_noise) { out[0] = out[1] = out[2] = out[3] = 0; return; }
   uint32_t r[4];
-  ote_rng(E, e, OTE_RNG_MOTOR, (uint32_t)slot, (uint32_t)sub, (uint32_t)E->envs[e].episode, step_index, r);
-  /* Box-Muller, two pairs */
-  real r0 = sqrt((real)-2 * log(u01_open(r[0]))), a0 = (real)2 * OTE_PI * u01(r[1]);
-  real r1 = sqrt((real)-2 * log(u01_open(r[2]))), a1 = (real)2 * OTE_PI * u01(r[3]);
+  ote_rng(E, e, OTE_RNG_MOTOR, (uint32_t)slot, (uint32_t)(sub >> 1), (uint32_t)E->envs[e].episode, step_index, r);
+  const uint32_t a = r[(sub & 1) * 2 + 0], b = r[(sub & 1) * 2 + 1];
+  const real k16 = (real)(1.0 / 65536.0);
+  real r0 = sqrt((real)-2 * log(((real)(a & 0xFFFFu) + (real)0.5) * k16)), a0 = (real)2 * OTE_PI * ((real)(a >> 16) * k16);
+  real r1 = sqrt((real)-2 * log(((real)(b & 0xFFFFu) + (real)0.5) * k16)), a1 = (real)2 * OTE_PI * ((real)(b >> 16) * k16);
   out[0] = r0 * cos(a0); out[1] = r0 * sin(a0); out[2] = r1 * cos(a1); out[3] = r1 * sin(a1);
 }
 
