@@ -43,13 +43,26 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """Threads the CPU baseline may use: the cgroup CPU quota when there is one, else the affinity mask, capped
+    at the 16-core share a one-GPU box gets (oversubscribing 256 visible CPUs would only thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("TE_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(task: str, overrides: dict, action_seed: int, seconds: float):
     """The oracle (scalar C restatement, float64, OpenMP over envs) timed on this box's host cores on a
     bounded sample of the same workload.  A reported baseline, not the optimisation target."""
     from oracle import te_oracle as O
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n = 4096
+    cores = host_cores()
+    n = 8192
     cfg = O.default_config(task, n_envs=n, **overrides)
     env = O.OracleEnv(cfg, "f64", threads=cores)
     env.reset()
@@ -111,8 +124,8 @@ def main():
         one_step(i)
     torch.cuda.synchronize(device)
     use_events = not args.no_profile_events
-    if use_events:
-        env.profile_begin(args.steps)
+    if use_events:  # HIP events bracket the two kernels of the first <= 64 timed steps (each record costs ~3 us of stream time)
+        env.profile_begin(min(args.steps, 64))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -135,9 +148,11 @@ def main():
         D = cfg.n_drones
         total_env_steps = world * n_local * args.steps
         value = total_env_steps / elapsed
-        alg = _lib.algorithmic_bytes_per_env_step(cfg)          # whole env.step
-        alg_k1 = D * 2 * 176 + 16                                 # state planes read + written, action read
-        alg_k2 = alg - alg_k1                                     # env scalars r/w + observation written
+        alg = _lib.algorithmic_bytes_per_env_step(cfg)          # whole env.step = 8108 B for stage03
+        # split by the kernel that moves each term: the sub-step kernel reads + writes the drone state,
+        # reads the action and streams the LIDAR planes; the engage/observe kernel moves the rest
+        alg_k1 = D * 2 * 176 + 16 + 3 * 338 * 4
+        alg_k2 = alg - alg_k1
         out = {
             "metric": "env-steps/sec (whole job), random-action rollout",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

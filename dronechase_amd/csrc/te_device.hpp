@@ -34,7 +34,16 @@ struct Params {
   uint32_t* dstate;
   uint32_t* estate;
   int N, Npad, D;
+  unsigned long long* dbg;  // phase stamps of one block (diagnostic builds with -DTE_DEBUG_STAMPS only; else unused)
 };
+#ifdef TE_DEBUG_STAMPS
+#define TE_STAMP(p, blk, idx)                                                                     \
+  do {                                                                                            \
+    if ((p).dbg && blockIdx.x == (blk) && threadIdx.x == 0) (p).dbg[(idx)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define TE_STAMP(p, blk, idx) do {} while (0)
+#endif
 
 #define TE_DEV __device__ __forceinline__
 

@@ -228,7 +228,7 @@ TE_DEV void stage_block(const Params& p, uint32_t* sm, const Rows& r, int env0) 
   const size_t col = (size_t)env0 + lane;  // planes are padded to Npad (multiple of 64): always in bounds
   const uint32_t inv_d = (65536u + (uint32_t)p.D - 1u) / (uint32_t)p.D;
   const int n = r.staged();
-  constexpr int B = 16;
+  constexpr int B = 32;  // 4 waves x 32 >= 112 rows (D = 11): the whole block is staged in ONE round of loads
   for (int base = wave; base < n; base += B * nw) {
     uint32_t vals[B];
 #pragma unroll
@@ -252,16 +252,13 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
   const int nvalid = min(kEPB, p.N - env0);
   // The [N,3,13,26] LIDAR buffer has already been filled with ones by the sub-step kernel's waves
   // (FillJob): only the hit cells are patched here.
+  TE_STAMP(p, 500, 0);
   stage_block(p, sm, r, env0);
-#if defined(TE_K2_STOP) && TE_K2_STOP == 1
-  if (sm[threadIdx.x] == 0x12345u) o.reward[0] = 1.0f; return;
-#endif
   __syncthreads();
+  TE_STAMP(p, 500, 1);
   precompute_block(p.cfg, sm, r);
-#if defined(TE_K2_STOP) && TE_K2_STOP == 2
-  if (sm[threadIdx.x + 2000] == 0x12345u) o.reward[0] = 1.0f; return;
-#endif
   __syncthreads();
+  TE_STAMP(p, 500, 2);
   if (threadIdx.x < kEPB && (int)threadIdx.x < nvalid) {
     const int lane = threadIdx.x;
     SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + lane, r.P}, sm, lane, r, p.D, r.P, env0 + lane, true};
@@ -270,13 +267,34 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
     else if (FAMILY == FAM_STAGE02) stage02_logic(p.cfg, v, a, o);
     else level4_logic(p.cfg, v, a, o);
   }
+  TE_STAMP(p, 500, 3);
   __syncthreads();
-  if (o.term.lidar) {  // terminal tiles of auto-reset envs (rare): ones, drained, then patched
+  TE_STAMP(p, 500, 4);
+  if (FAMILY == FAM_LEVEL4) {
+    // epilogue split by wave: wave 0 writes the inertial / last_action rows while waves 1..3 prepare the scripted
+    // commands of the next step, one (env, drone) item per thread iteration
+    if (threadIdx.x < 64) emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, 64);
+    else
+      for (int it = threadIdx.x - 64; it < kEPB * (p.D - 1); it += blockDim.x - 64) {
+        const int l = it & (kEPB - 1), s = 1 + it / kEPB;
+        if (l >= nvalid) continue;
+        SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + l, r.P}, sm, l, r, p.D, r.P, env0 + l, sm[r.prevalid() * kEPB + l] != 0u};
+        prepare_slot(p.cfg, v, s);
+      }
+  } else {
+    emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, blockDim.x);
+  }
+  TE_STAMP(p, 500, 5);
+  // terminal tiles of auto-reset envs (rare, block-uniform test): ones, drained, then patched
+  const bool lane_done = threadIdx.x < kEPB && sm[r.done() * kEPB + threadIdx.x] != 0u;
+  if (o.term.lidar && __syncthreads_or(lane_done ? 1 : 0)) {
     stream_terminal_ones(sm, r, o.term.lidar, env0, nvalid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  TE_STAMP(p, 500, 6);
   patch_hits(p.cfg, sm, r, o.obs.lidar, o.term.lidar, env0, nvalid);
+  TE_STAMP(p, 500, 7);
 }
 
 // Background of the LIDAR observation: all ones (LIDARSpec.empty_sphere, angle_grid.py:95-104).  Pure
@@ -302,15 +320,11 @@ __global__ __launch_bounds__(256) void observe_kernel(Params p, ObsOut o) {
   if (threadIdx.x < kEPB && (int)threadIdx.x < nvalid) {
     const int lane = threadIdx.x;
     SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + lane, r.P}, sm, lane, r, p.D, r.P, env0 + lane, true};
-    const int step = v.egi(TE_E_STEP);
-    float in[TE_OBS_INERTIAL_WORDS], la[4];
-    inertial_obs(p.cfg, v, step, in);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) la[k] = v.egf(TE_E_LAST_ACTION + k);
     // right after a reset the Delta=1 snapshot does not exist yet: empty sphere
-    if (step != 0) sm[r.hitmask() * kEPB + lane] = resolve_hits(v);
-    write_obs_rows(o, v.env, in, la);
+    if (v.egi(TE_E_STEP) != 0) sm[r.hitmask() * kEPB + lane] = resolve_hits(v);
   }
+  __syncthreads();
+  emit_rows(p.cfg, sm, r, o, env0, nvalid, threadIdx.x, blockDim.x);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ones must have landed before any patch
   __syncthreads();
   patch_hits(p.cfg, sm, r, o.lidar, nullptr, env0, nvalid);
@@ -451,6 +465,11 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     delete e;
     return fail("te_create: hipMalloc failed");
   }
+  e->p.dbg = nullptr;
+#ifdef TE_DEBUG_STAMPS
+  if (hipMalloc(&e->p.dbg, 64 * sizeof(unsigned long long)) != hipSuccess) e->p.dbg = nullptr;
+  else (void)hipMemset(e->p.dbg, 0, 64 * sizeof(unsigned long long));
+#endif
   TE_HIP(hipMemsetAsync(e->p.dstate, 0, dwords * 4, nullptr));
   TE_HIP(hipMemsetAsync(e->p.estate, 0, ewords * 4, nullptr));
   hipLaunchKernelGGL(init_planes, dim3(256), dim3(256), 0, nullptr, e->p);
@@ -470,6 +489,7 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
   (void)hipFree(e->p.dstate);
   (void)hipFree(e->p.estate);
+  if (e->p.dbg) (void)hipFree(e->p.dbg);
   delete e;
 }
 
@@ -625,6 +645,18 @@ __attribute__((visibility("default"))) int te_profile_end(te_env* e, float* subs
   if (engage_observe_ms) *engage_observe_ms = n ? (float)(b / n) : 0.0f;
   if (n_steps) *n_steps = n;
   e->prof_cap = 0; e->prof_used = 0;
+  return 0;
+}
+
+// Diagnostic builds (-DTE_DEBUG_STAMPS): s_memrealtime (100 MHz) stamps one workgroup wrote at its phase
+// boundaries during the last launch; all zeros in a normal build.
+__attribute__((visibility("default"))) int te_debug_stamps(te_env* e, uint64_t* out_host, int32_t n) {
+  if (!e || !out_host || n < 1 || n > 64) return fail("te_debug_stamps: bad argument");
+  memset(out_host, 0, (size_t)n * sizeof(uint64_t));
+  if (!e->p.dbg) return 0;
+  DeviceGuard guard(e->device);
+  TE_HIP(hipDeviceSynchronize());
+  TE_HIP(hipMemcpy(out_host, e->p.dbg, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -50,9 +50,10 @@ struct Rows {
   TE_DEV int lrhat() const { return lcell() + D; }          // D   : normalised range of drone j
   TE_DEV int hitmask() const { return lrhat() + D; }        // 1   : bit j = drone j owns its cell in this step's sphere
   TE_DEV int done() const { return hitmask() + 1; }         // 1   : env auto-reset this step
-  TE_DEV int total() const { return done() + 1; }
+  TE_DEV int prevalid() const { return done() + 1; }        // 1   : distance / zone rows still valid after the logic
+  TE_DEV int total() const { return prevalid() + 1; }
 };
-__host__ __device__ inline int lds_rows(int D, int P) { return 9 * D + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 4; }
+__host__ __device__ inline int lds_rows(int D, int P) { return 9 * D + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 5; }
 
 struct SView {
   GView g; uint32_t* sm; int lane; Rows r;
@@ -244,52 +245,58 @@ template <class V> TE_DEV bool building_path_clear(const te_config& c, const V& 
     if (((mask >> p) & 1u) && inside_cone(obs_pos(v, p), me, b, degrees)) return false;
   return true;
 }
-template <class V> TE_DEV void prepare_level4_commands(const te_config& c, const V& v) {
-  const int Pn = c.n_pursuers, D = v.D;
+// command of ONE scripted drone `s` (invader: KamikazeNavigator.update; ally: LoyalWingmanBehaviorTree.update)
+template <class V> TE_DEV void prepare_slot(const te_config& c, const V& v, int s) {
+  const int Pn = c.n_pursuers;
+  if (!v.gi(TE_D_ARMED, s)) return;
   const uint32_t S = (uint32_t)v.egi(TE_E_SNAP_MASK);
-  const int step = v.egi(TE_E_STEP);
-  const uint32_t pursuer_bits = S & ((1u << Pn) - 1u);
-  // KamikazeNavigator.update (…air_combat_only.py:68-78): transition registered, OLD state executes
-  for (int j = Pn; j < D; ++j) {
-    if (!v.gi(TE_D_ARMED, j)) continue;
-    int state = v.gi(TE_D_NAV_STATE, j), next = state;
-    V3 me = obs_pos(v, j);
+  if (s >= Pn) {  // KamikazeNavigator.update (…air_combat_only.py:68-78): transition registered, OLD state executes
+    const uint32_t pursuer_bits = S & ((1u << Pn) - 1u);
+    int state = v.gi(TE_D_NAV_STATE, s), next = state;
+    V3 me = obs_pos(v, s);
     if (state == TE_NAV_WAIT) {
-      if (building_path_clear(c, v, S, j, 60.0f)) next = TE_NAV_COLLIDE_BUILDING;
+      if (building_path_clear(c, v, S, s, 60.0f)) next = TE_NAV_COLLIDE_BUILDING;
       else if (pursuer_bits) next = TE_NAV_COLLIDE_WINGMAN;
-      v.sf(TE_X_CMD + 0, j, 0.0f); v.sf(TE_X_CMD + 1, j, 0.0f); v.sf(TE_X_CMD + 2, j, 0.0f);  // hover (:163)
+      v.sf(TE_X_CMD + 0, s, 0.0f); v.sf(TE_X_CMD + 1, s, 0.0f); v.sf(TE_X_CMD + 2, s, 0.0f);  // hover (:163)
     } else if (state == TE_NAV_COLLIDE_WINGMAN) {
       if (!pursuer_bits) next = TE_NAV_COLLIDE_BUILDING;
-      int t = closest_pursuer(v, S, j);
+      int t = closest_pursuer(v, S, s);
       V3 target = t >= 0 ? obs_pos(v, t) : V3{0, 0, 0};
-      set_cmd_toward(v, j, me, target, c.invader_speed);
+      set_cmd_toward(v, s, me, target, c.invader_speed);
     } else {
-      if (!building_path_clear(c, v, S, j, 45.0f)) next = TE_NAV_COLLIDE_WINGMAN;
-      set_cmd_toward(v, j, me, V3{c.building_position[0], c.building_position[1], c.building_position[2]}, c.invader_speed);
+      if (!building_path_clear(c, v, S, s, 45.0f)) next = TE_NAV_COLLIDE_WINGMAN;
+      set_cmd_toward(v, s, me, V3{c.building_position[0], c.building_position[1], c.building_position[2]}, c.invader_speed);
     }
-    v.si(TE_X_NAV_NEXT, j, next);
+    v.si(TE_X_NAV_NEXT, s, next);
+    return;
   }
-  // drive_loyalwingmen: get_armed_pursuers()[1:] (exp03_vFinal_task.py:238-244)
-  const bool agent_armed = v.gi(TE_D_ARMED, 0) != 0;
-  for (int a = agent_armed ? 1 : 2; a < Pn; ++a) {
-    if (!v.gi(TE_D_ARMED, a)) continue;
-    if (c.ally_policy == TE_ALLY_BT) {  // LoyalWingmanBehaviorTree (loyalwingman_navigator.py:238-352)
-      V3 me = obs_pos(v, a);
-      if (gun_available(c, v.gi(TE_D_MUNITION, a), v.gi(TE_D_LAST_FIRED, a), step)) {
-        float dm;
-        int t = ((S >> a) & 1u) ? closest_invader(v, S, a, dm) : -1;
-        V3 target = t >= 0 ? obs_pos(v, t) : V3{0, 0, 0};
-        set_cmd_toward(v, a, me, target, c.ally_speed);
-      } else {
-        set_cmd_toward(v, a, me, V3{v.gf(TE_D_FORMATION, a), v.gf(TE_D_FORMATION + 1, a), v.gf(TE_D_FORMATION + 2, a)}, c.ally_speed);
-      }
-    } else if (c.ally_policy == TE_ALLY_FROZEN) {  // exp04_vFinal_task.py:240-242: drive([0,0,0,1])
-      v.sf(TE_X_CMD + 0, a, 0.0f); v.sf(TE_X_CMD + 1, a, 0.0f); v.sf(TE_X_CMD + 2, a, 0.0f);
+  // drive_loyalwingmen: get_armed_pursuers()[1:] (exp03_vFinal_task.py:238-244): with the agent dead the
+  // first armed ally is the one that is skipped
+  if (s == 0) return;
+  if (!v.gi(TE_D_ARMED, 0)) {
+    int first = -1;
+    for (int a = 1; a < Pn; ++a) if (v.gi(TE_D_ARMED, a)) { first = a; break; }
+    if (s == first) return;
+  }
+  if (c.ally_policy == TE_ALLY_BT) {  // LoyalWingmanBehaviorTree (loyalwingman_navigator.py:238-352)
+    V3 me = obs_pos(v, s);
+    if (gun_available(c, v.gi(TE_D_MUNITION, s), v.gi(TE_D_LAST_FIRED, s), v.egi(TE_E_STEP))) {
+      float dm;
+      int t = ((S >> s) & 1u) ? closest_invader(v, S, s, dm) : -1;
+      V3 target = t >= 0 ? obs_pos(v, t) : V3{0, 0, 0};
+      set_cmd_toward(v, s, me, target, c.ally_speed);
     } else {
-      v.sf(TE_X_CMD + 0, a, v.gf(TE_D_SETPOINT + 0, a)); v.sf(TE_X_CMD + 1, a, v.gf(TE_D_SETPOINT + 1, a));
-      v.sf(TE_X_CMD + 2, a, v.gf(TE_D_SETPOINT + 3, a));
+      set_cmd_toward(v, s, me, V3{v.gf(TE_D_FORMATION, s), v.gf(TE_D_FORMATION + 1, s), v.gf(TE_D_FORMATION + 2, s)}, c.ally_speed);
     }
+  } else if (c.ally_policy == TE_ALLY_FROZEN) {  // exp04_vFinal_task.py:240-242: drive([0,0,0,1])
+    v.sf(TE_X_CMD + 0, s, 0.0f); v.sf(TE_X_CMD + 1, s, 0.0f); v.sf(TE_X_CMD + 2, s, 0.0f);
+  } else {
+    v.sf(TE_X_CMD + 0, s, v.gf(TE_D_SETPOINT + 0, s)); v.sf(TE_X_CMD + 1, s, v.gf(TE_D_SETPOINT + 1, s));
+    v.sf(TE_X_CMD + 2, s, v.gf(TE_D_SETPOINT + 3, s));
   }
+}
+template <class V> TE_DEV void prepare_level4_commands(const te_config& c, const V& v) {
+  for (int s = 1; s < v.D; ++s) prepare_slot(c, v, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -309,7 +316,7 @@ template <class V> TE_DEV void level4_refresh_snapshot(const V& v) {
   for (int s = 0; s < v.D; ++s) v.si(TE_D_NAV_STATE, s, TE_NAV_WAIT);  // navigators reset()
 }
 // Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146, exp03_vFinal_task.py:255-274)
-template <class V> TE_DEV void level4_reset_env(const te_config& c, const V& v) {
+template <class V> TE_DEV void level4_reset_env(const te_config& c, const V& v, bool prepare = true) {
   const uint32_t episode = (uint32_t)(v.egi(TE_E_EPISODE) + 1);
   v.esi(TE_E_EPISODE, (int)episode);
   v.esi(TE_E_STEP, 0); v.esi(TE_E_MAX_STEP, c.max_step); v.esi(TE_E_ROUND, 1);
@@ -324,7 +331,7 @@ template <class V> TE_DEV void level4_reset_env(const te_config& c, const V& v) 
     respawn_armed(c, v, p, level4_position(c, c.pursuer_spawn_radius, u01(r.x), u01(r.y)));
   }
   level4_refresh_snapshot(v);
-  prepare_level4_commands(c, v);
+  if (prepare) prepare_level4_commands(c, v);
 }
 
 // stage02 ----------------------------------------------------------------------------------------
@@ -427,10 +434,10 @@ template <class V> TE_DEV void stage01_reset_env(const te_config& c, const V& v)
   v.esi(TE_E_SNAP_MASK, (int)armed_mask(v));
 }
 
-template <int FAMILY, class V> TE_DEV void reset_env(const te_config& c, const V& v) {
+template <int FAMILY, class V> TE_DEV void reset_env(const te_config& c, const V& v, bool prepare = true) {
   if (FAMILY == FAM_STAGE01) stage01_reset_env(c, v);
   else if (FAMILY == FAM_STAGE02) stage02_reset_env(c, v);
-  else level4_reset_env(c, v);
+  else level4_reset_env(c, v, prepare);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -580,19 +587,45 @@ template <int FAMILY, class FinishFn>
 TE_DEV void emit_and_finish(const te_config& c, const SView& v, int step, bool term, const StepOut& o, FinishFn finish) {
   const bool to_terminal = term && c.auto_reset;
   v.sm[v.at(v.r.done())] = to_terminal ? 1u : 0u;
-  float in[TE_OBS_INERTIAL_WORDS], la[4];
-  inertial_obs(c, v, step, in);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) la[k] = v.egf(TE_E_LAST_ACTION + k);
   v.sm[v.at(v.r.hitmask())] = resolve_hits(v);  // compute_observation happens before on_step_end
-  finish();
-  if (to_terminal) {  // SB3 VecEnv auto-reset: terminal observation aside, reset observation in the main buffers
+  if (to_terminal) {  // SB3 VecEnv auto-reset: the terminal observation goes aside (rare: straight from this lane)
+    float in[TE_OBS_INERTIAL_WORDS], la[4];
+    inertial_obs(c, v, step, in);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) la[k] = v.egf(TE_E_LAST_ACTION + k);
     write_obs_rows(o.term, v.env, in, la);
-    reset_env<FAMILY>(c, v);
-    inertial_obs(c, v, 0, in);
-    la[0] = la[1] = la[2] = la[3] = 0.0f;
   }
-  write_obs_rows(o.obs, v.env, in, la);
+  finish();
+  if (to_terminal) reset_env<FAMILY>(c, v, false);
+  // the main inertial / last_action rows (post-reset values for an auto-reset env) and the scripted
+  // commands of the next step are produced by the whole block afterwards (emit_rows / prepare phase)
+  v.sm[v.at(v.r.prevalid())] = v.pre_valid ? 1u : 0u;
+}
+
+// Block-parallel epilogue 1: inertial [nvalid,15] and last_action [nvalid,4] rows from the LDS copy of the
+// agent's IMU read / gun / env record, one output word per thread iteration, coalesced.
+TE_DEV void emit_rows(const te_config& c, const uint32_t* sm, const Rows& r, const ObsOut& o, int env0, int nvalid,
+                      int tid, int nthreads) {
+  const int D = r.D;
+  if (o.inertial)
+    for (int j = tid; j < nvalid * TE_OBS_INERTIAL_WORDS; j += nthreads) {
+      const int l = j / TE_OBS_INERTIAL_WORDS, k = j - l * TE_OBS_INERTIAL_WORDS;
+      float val;
+      if (k < 3) val = clampf(__uint_as_float(sm[(r.obs_pos() + k * D) * kEPB + l]) / c.dome_radius, -1.0f, 1.0f);
+      else if (k < 6) val = clampf(__uint_as_float(sm[(r.agent() + 3 + (k - 3)) * kEPB + l]) / c.max_speed, -1.0f, 1.0f);
+      else if (k < 9) val = clampf(__uint_as_float(sm[(r.agent() + (k - 6)) * kEPB + l]) / kPi, -1.0f, 1.0f);
+      else if (k < 12) val = clampf(__uint_as_float(sm[(r.agent() + 6 + (k - 9)) * kEPB + l]) / (2.0f * kPi), -1.0f, 1.0f);
+      else {
+        float g[3];
+        gun_state(c, (int)sm[(r.flags() + 1 * D) * kEPB + l], (int)sm[(r.flags() + 2 * D) * kEPB + l],
+                  (int)sm[(r.env() + TE_E_STEP) * kEPB + l], max_munition_of(c, 0), g);
+        val = g[k - 12];
+      }
+      o.inertial[(size_t)env0 * TE_OBS_INERTIAL_WORDS + j] = val;
+    }
+  if (o.last_action)
+    for (int j = tid; j < nvalid * 4; j += nthreads)
+      o.last_action[(size_t)env0 * 4 + j] = __uint_as_float(sm[(r.env() + TE_E_LAST_ACTION + (j & 3)) * kEPB + (j >> 2)]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -651,9 +684,6 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
   for (int j = Pn; j < D; ++j)
     if (((S >> j) & 1u) && in_origin(c, v, j)) disarm(v, j);
 
-#if defined(TE_K2_STOP) && TE_K2_STOP == 3
-  o.reward[v.env] = (float)(agent_kills + deads); return;
-#endif
   // compute_reward (:423-515)
   float reward;
   const V3 apos = obs_pos(v, 0);
@@ -705,9 +735,6 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
   o.reward[v.env] = reward;
   o.done[v.env] = term ? 1 : 0;
   reinterpret_cast<int4*>(o.info)[v.env] = make_int4(agent_kills, allies_kills, deads, round);
-#if defined(TE_K2_STOP) && TE_K2_STOP == 4
-  return;
-#endif
   emit_and_finish<FAM_LEVEL4>(c, v, step, term, o, [&]() {
     // on_step_end (:321-333): next wave when this one is cleared and a pursuer is alive
     if (!term && armed_invaders == 0 && armed_pursuers > 0) {
@@ -716,9 +743,6 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
       level4_setup_round(c, v, next, episode);
       level4_refresh_snapshot(v);
     }
-#if !(defined(TE_K2_STOP) && TE_K2_STOP == 5)
-    if (!(term && c.auto_reset)) prepare_level4_commands(c, v);
-#endif
   });
 }
 

@@ -232,6 +232,10 @@ int te_algorithmic_bytes_per_env_step(const te_config* cfg, size_t* out_bytes);
 int te_profile_begin(te_env* env, int32_t max_steps);
 int te_profile_end(te_env* env, float* substeps_ms, float* engage_observe_ms, int32_t* n_steps);
 
+/* Diagnostic builds only (-DTE_DEBUG_STAMPS): 100 MHz phase stamps of one workgroup of the last te_step;
+ * zeros otherwise.  out_host is HOST memory. */
+int te_debug_stamps(te_env* env, uint64_t* out_host, int32_t n);
+
 int te_abi_version(void);
 const char* te_last_error(void);
 

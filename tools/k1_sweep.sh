@@ -1,7 +1,4 @@
-for w in 0 5; do
-  flags="[]"; [ "$w" != "0" ] && flags="['-DTE_K1_WAVES=$w']"
-  python -c "
+python -c "
 from dronechase_amd.build import build_library
-build_library(force=True, extra_flags=$flags)" >/dev/null 2>&1
-  echo "waves_per_eu=$w: $(python tools/k2_probe.py 2>/dev/null | sed -n 1p)"
-done
+build_library(force=True, extra_flags=['-DTE_DEBUG_STAMPS=1'])" >/dev/null 2>&1
+python tools/k2_stamps.py; python tools/k2_stamps.py 4096

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Phase breakdown of one engage/observe workgroup (needs a -DTE_DEBUG_STAMPS build)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C, numpy as np, torch
+from dronechase_amd import default_config
+from dronechase_amd.batched_env import BatchedEnv
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+env = BatchedEnv(default_config("stage03", n_envs=N), "cuda:0")
+a = torch.empty((N, 4), device="cuda:0")
+env.reset()
+names = ["stage", "precompute", "logic", "barrier", "rows", "prepare", "patch"]
+acc = np.zeros(7)
+for i in range(60):
+    env.random_actions(1, i, out=a); env.step(a)
+    if i >= 20:
+        out = (C.c_uint64 * 8)()
+        env.L.te_debug_stamps(env._h, out, 8)
+        t = np.array(list(out), dtype=np.float64)
+        acc += np.diff(t) * 0.01  # 100 MHz -> us
+print("K2 phases (us, block 500):", {n: round(v / 40, 2) for n, v in zip(names, acc)}, "sum", round(acc.sum() / 40, 2))
