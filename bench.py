@@ -119,13 +119,22 @@ def main():
         env.random_actions(args.action_seed, i, out=actions)
         env.step(actions, terminal=True)
 
+    def armed_per_env() -> float:
+        """Mean number of armed drones per env (disarmed slots are not flown: they cost one flag load)."""
+        from dronechase_amd import config as K
+        w = env.get_state()
+        D = cfg.n_drones
+        return float((w[: n_local * D * K.DRONE_WORDS].view(n_local, D, K.DRONE_WORDS)[:, :, K.D["ARMED"]] != 0).float().sum(1).mean().item())
+
     env.reset()
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize(device)
     use_events = not args.no_profile_events
+    n_events = min(args.steps, 64)
+    armed_begin = armed_per_env() if rank == 0 else 0.0
     if use_events:  # HIP events bracket the two kernels of the first <= 64 timed steps (each record costs ~3 us of stream time)
-        env.profile_begin(min(args.steps, 64))
+        env.profile_begin(n_events)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -138,6 +147,7 @@ def main():
     elapsed = time.perf_counter() - t0
     k1_ms, k2_ms, n_prof = env.profile_end() if use_events else (0.0, 0.0, 0)
     done_frac = float(env.done.float().mean().item())
+    armed_end = armed_per_env() if rank == 0 else 0.0
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -148,11 +158,17 @@ def main():
         D = cfg.n_drones
         total_env_steps = world * n_local * args.steps
         value = total_env_steps / elapsed
-        alg = _lib.algorithmic_bytes_per_env_step(cfg)          # whole env.step = 8108 B for stage03
-        # split by the kernel that moves each term: the sub-step kernel reads + writes the drone state,
-        # reads the action and streams the LIDAR planes; the engage/observe kernel moves the rest
-        alg_k1 = D * 2 * 176 + 16 + 3 * 338 * 4
-        alg_k2 = alg - alg_k1
+        alg_all = _lib.algorithmic_bytes_per_env_step(cfg)      # whole env.step with all D drones armed = 8108 B for stage03
+        # Only ARMED drones are flown (a disarmed slot costs one flag load), and in a random-action rollout most invader
+        # slots are empty for the first few hundred steps, so the algorithmic bytes are priced at the armed count that
+        # was actually there: the mean of the census taken right before and right after the timed region, weighted to the
+        # event-timed window (its first n_events steps).  DESIGN.md 4 has the per-term table.
+        frac_window = 0.5 * n_events / max(args.steps, 1)
+        armed = armed_begin + (armed_end - armed_begin) * frac_window
+        per_drone = 2 * 176                                        # sub-step kernel: state read + written per armed drone
+        alg_k1 = armed * per_drone + 16 + 3 * 338 * 4              # + action + LIDAR background
+        alg_k2 = alg_all - (D * per_drone + 16 + 3 * 338 * 4)      # engage/observe kernel: the rest
+        alg = alg_k1 + alg_k2
         out = {
             "metric": "env-steps/sec (whole job), random-action rollout",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,11 +194,12 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": dom_bytes * n_local, "avg_launch_ms": dom_ms,
-                               "launches_timed": n_prof}
+                               "launches_timed": n_prof, "armed_drones_per_env": armed,
+                               "armed_drones_per_env_begin_end": [armed_begin, armed_end]}
             step_ms = k1_ms + k2_ms
             out["roofline_env_step"] = {"bound": "hbm", "achieved": alg * n_local / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": alg * n_local / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "algorithmic_bytes_per_env_step": alg, "substeps_kernel_ms": k1_ms,
+                                        "algorithmic_bytes_per_env_step": alg, "algorithmic_bytes_all_armed": alg_all, "substeps_kernel_ms": k1_ms,
                                         "engage_observe_kernel_ms": k2_ms}
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -36,8 +36,11 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
     subprocess.run(["gcc", "-O2", "-fPIC", "-fvisibility=hidden", "-c", os.path.join(CSRC, "te_config.c"), "-o", obj],
                    check=True)
     hobj = os.path.join(CSRC, "te_env.o")
+    # -fno-slp-vectorize: the SLP vectorizer turns the scalar fp32 physics into v_pk_* pairs; on gfx950 that saves
+    # no instructions here (the pairs cost as many v_mov to assemble) but needs 95 instead of 72 VGPRs in the
+    # sub-step kernel, i.e. 5 instead of 7 waves per SIMD
     compile_cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-gpu-rdc",
-                   "-Wall", "-Wno-unused-function", *extra_flags, "-c", os.path.join(CSRC, "te_env.hip"), "-o", hobj]
+                   "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", *extra_flags, "-c", os.path.join(CSRC, "te_env.hip"), "-o", hobj]
     link_cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", hobj, obj, "-o", LIB + ".tmp", "-lm"]
     for cmd in (compile_cmd, link_cmd):
         if verbose:

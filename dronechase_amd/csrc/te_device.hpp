@@ -58,29 +58,40 @@ struct Planes {
   TE_DEV int32_t& ei(int w) const { return reinterpret_cast<int32_t*>(e)[(size_t)w * Npad + env]; }
 };
 
-// one drone slot of one env, 32-bit indexing (te_create rejects state planes beyond 2^32 bytes)
+// One drone slot of one env for the sub-step kernel, through buffer instructions: a 128-bit resource per state
+// array (SGPRs), ONE shared 32-bit VGPR byte offset per lane, the plane as the scalar offset.  Written with the
+// raw-buffer builtins because the equivalent pointer arithmetic only sometimes lowers to "saddr + voffset":
+// when it does not, every plane gets its own 64-bit VGPR address pair and the kernel loses two waves per SIMD.
+// te_create rejects state arrays beyond 2^32 bytes; out-of-range offsets read 0 / drop the store.
 struct SlotLane {
-  uint32_t* d; uint32_t* e; uint32_t plane_stride, off, npad, env;
-  // address = (wave-uniform plane base: SGPR pair) + (ONE shared 32-bit VGPR byte offset, zero-extended):
-  // lowers to global_load/store ... saddr with the same offset register for every plane
-  TE_DEV float& f(int w) const {
-    char* plane = reinterpret_cast<char*>(d) + (size_t)((uint32_t)w * plane_stride) * 4u;
-    return *reinterpret_cast<float*>(plane + (size_t)(uint32_t)(off << 2));
-  }
-  TE_DEV int32_t& i(int w) const { return reinterpret_cast<int32_t&>(f(w)); }
-  TE_DEV int32_t& ei(int w) const {
-    char* plane = reinterpret_cast<char*>(e) + (size_t)((uint32_t)w * npad) * 4u;
-    return *reinterpret_cast<int32_t*>(plane + (size_t)(uint32_t)(env << 2));
-  }
+  __amdgpu_buffer_rsrc_t d, e;
+  uint32_t plane_bytes, off_bytes, eplane_bytes, env_bytes;
+  TE_DEV SlotLane(uint32_t* dstate, uint32_t* estate, uint32_t D, uint32_t npad, uint32_t slot, uint32_t env, uint32_t d_words,
+                  uint32_t e_words)
+      : d(__builtin_amdgcn_make_buffer_rsrc(dstate, 0, (int)(d_words * 4u), 0x00020000)),
+        e(__builtin_amdgcn_make_buffer_rsrc(estate, 0, (int)(e_words * 4u), 0x00020000)),
+        plane_bytes(D * npad * 4u), off_bytes((slot * npad + env) * 4u), eplane_bytes(npad * 4u), env_bytes(env * 4u) {}
+  TE_DEV float lf(int w) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d, (int)off_bytes, (int)((uint32_t)w * plane_bytes), 0)); }
+  TE_DEV int32_t li(int w) const { return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(d, (int)off_bytes, (int)((uint32_t)w * plane_bytes), 0); }
+  TE_DEV void sf(int w, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), d, (int)off_bytes, (int)((uint32_t)w * plane_bytes), 0); }
+  TE_DEV void si(int w, int32_t v) const { __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, d, (int)off_bytes, (int)((uint32_t)w * plane_bytes), 0); }
+  TE_DEV int32_t lei(int w) const { return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(e, (int)env_bytes, (int)((uint32_t)w * eplane_bytes), 0); }
 };
 
 // ---------------------------------------------------------------- Philox4x32-10
 struct U4 { uint32_t x, y, z, w; };
+// 32x32 -> 64-bit product in ONE quarter-rate instruction (hipcc emits v_mul_hi_u32 + v_mul_lo_u32, two of them)
+TE_DEV void mul_hi_lo(uint32_t a, uint32_t m, uint32_t& hi, uint32_t& lo) {
+  uint64_t prod;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(prod) : "v"(a), "s"(m) : "vcc");
+  hi = (uint32_t)(prod >> 32); lo = (uint32_t)prod;
+}
 TE_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t hi0, lo0, hi1, lo1;
+    mul_hi_lo(c0, 0xD2511F53u, hi0, lo0);
+    mul_hi_lo(c2, 0xCD9E8D57u, hi1, lo1);
     uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -216,6 +227,30 @@ TE_DEV float pid(float kp, float ki, float kd, float lim, float T, float invT, f
   return clampf(kp * err + I + Dv, -lim, lim);
 }
 
+// Motor noise: 4 standard normals per sub-step.  One Philox4x32-10 call (40 quarter-rate integer multiplies)
+// serves TWO consecutive sub-steps: 128 bits = eight 16-bit uniforms = four Box-Muller pairs on the native
+// log / sqrt / sin / cos.  Sub-step `sub` uses words {x,y} when even, {z,w} when odd, of call index sub >> 1.
+// The two words travel into substep() as they are and become normals only at the motor stage, so that no
+// float noise registers are live across the IMU / controller half of the sub-step.
+TE_DEV U4 motor_noise_bits(const te_config& c, int env, int slot, uint32_t episode, uint32_t step_index, int sub) {
+  // Same value as env_rng(c, env, RNG_MOTOR, slot, sub >> 1, episode, step_index).  The empty asm statements make
+  // the loop-invariant inputs opaque per call: otherwise the compiler hoists the invariant half of the first
+  // Philox rounds and all 20 round keys out of the sub-step loop, into ~8 VGPRs and ~20 SGPRs that stay live
+  // across it (97 -> 91 VGPRs, i.e. 4 -> 5 waves per SIMD, for three extra multiplies per call).
+  uint32_t k0 = (uint32_t)c.seed, k1 = (uint32_t)(c.seed >> 32);
+  asm volatile("" : "+s"(k0), "+s"(k1));
+  asm volatile("" : "+v"(episode), "+v"(step_index), "+v"(env));
+  const uint64_t g = (uint64_t)c.env_index_base + (uint64_t)env;
+  return philox4x32_10((uint32_t)g, RNG_MOTOR | ((uint32_t)slot << 8) | ((uint32_t)(sub >> 1) << 16) | ((uint32_t)(g >> 32) << 24),
+                       episode, step_index, k0, k1);
+}
+TE_DEV void motor_noise_from(uint32_t a, uint32_t b, float nz[4]) {
+  const float k16 = 1.0f / 65536.0f;
+  float r0 = fsqrt(-2.0f * ln(((float)(a & 0xFFFFu) + 0.5f) * k16)), r1 = fsqrt(-2.0f * ln(((float)(b & 0xFFFFu) + 0.5f) * k16));
+  float a0 = (float)(a >> 16) * k16, a1 = (float)(b >> 16) * k16;  // revolutions
+  nz[0] = r0 * cos_rev(a0); nz[1] = r0 * sin_rev(a0); nz[2] = r1 * cos_rev(a1); nz[3] = r1 * sin_rev(a1);
+}
+
 // One physics sub-step: IMU read -> cascaded PID (mode 6, or 7 when MODE7) -> motors + drag -> free-body
 // integration.  Replaces quadcopter.update_imu/update_control/update_physics + stepSimulation
 // (level4_simulation.py:87-98) for one armed drone.  `sp` = [a0, a1, yaw-rate, z] set-point.
@@ -226,9 +261,9 @@ TE_DEV float pid(float kp, float ki, float kd, float lim, float T, float invT, f
 //    right of q;
 //  * cos/sin(yaw) come from the first column of R instead of sincos(atan2(.));
 //  * sin/cos of the half rotation angle (< 0.5 rad per 1/240 s for any sane rate) by Taylor polynomials.
-template <bool MODE7, bool CAPTURE>
-TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float sp[4], const float nz[4], V3& pend_f,
-                    V3& pend_t) {
+template <bool MODE7, bool CAPTURE, bool NOISE>
+TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float sp[4], uint32_t noise_a, uint32_t noise_b,
+                    V3& pend_f, V3& pend_t) {
   const te_quad_params& qp = c.quad;
   const float T = c.control_dt, dt = k.dt;
   M3 R = rotation(b.q);
@@ -284,12 +319,13 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
     for (int i = 0; i < 4; ++i) pwm[i] += (1.0f - pwm[i]) * f;
   }
   // ---- motors (first-order lag, multiplicative noise, thrust/torque ~ rpm^2) + drag
-  float T_[4];
+  float T_[4], nz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (NOISE) motor_noise_from(noise_a, noise_b, nz);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float t = b.thr[i];
     t += k.k_motor * (pwm[i] - t);
-    t += nz[i] * t * k.noise_ratio;
+    if (NOISE) t += nz[i] * t * k.noise_ratio;
     b.thr[i] = t;
     T_[i] = t * t;
   }
@@ -330,23 +366,6 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
        q.w * dq.z + q.x * dq.y - q.y * dq.x + q.z * dq.w, q.w * dq.w - q.x * dq.x - q.y * dq.y - q.z * dq.z};
   float inv = rsq(n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w);
   b.q = Q4{n.x * inv, n.y * inv, n.z * inv, n.w * inv};
-}
-
-// Motor noise: 4 standard normals per sub-step.  One Philox4x32-10 call (40 quarter-rate integer multiplies)
-// serves TWO consecutive sub-steps: 128 bits = eight 16-bit uniforms = four Box-Muller pairs on the native
-// log / sqrt / sin / cos.  Sub-step `sub` uses words {x,y} when even, {z,w} when odd, of call index sub >> 1.
-TE_DEV U4 motor_noise_bits(const te_config& c, int env, int slot, uint32_t episode, uint32_t step_index, int sub) {
-  return env_rng(c, env, RNG_MOTOR, (uint32_t)slot, (uint32_t)(sub >> 1), episode, step_index);
-}
-TE_DEV void motor_noise_from(const U4& r, int sub, float nz[4]) {
-  const uint32_t a = (sub & 1) ? r.z : r.x, b = (sub & 1) ? r.w : r.y;
-  const float k16 = 1.0f / 65536.0f;
-  float r0 = fsqrt(-2.0f * ln(((float)(a & 0xFFFFu) + 0.5f) * k16)), r1 = fsqrt(-2.0f * ln(((float)(b & 0xFFFFu) + 0.5f) * k16));
-  float a0 = (float)(a >> 16) * k16, a1 = (float)(b >> 16) * k16;  // revolutions
-  nz[0] = r0 * cos_rev(a0); nz[1] = r0 * sin_rev(a0); nz[2] = r1 * cos_rev(a1); nz[3] = r1 * sin_rev(a1);
-}
-TE_DEV void motor_noise(const te_config& c, int env, int slot, uint32_t episode, uint32_t step_index, int sub, float nz[4]) {
-  motor_noise_from(motor_noise_bits(c, env, slot, episode, step_index, sub), sub, nz);
 }
 
 // Quadcopter.convert_command_to_setpoint (quadcopter.py:379-396): unit(direction) * magnitude

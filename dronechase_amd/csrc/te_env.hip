@@ -16,9 +16,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "te_logic.hpp"
@@ -28,8 +30,14 @@ namespace te {
 // ============================================================================================
 // K1: sub-steps
 // ============================================================================================
-// one wavefront per workgroup: the dispatcher can pack armed waves onto SIMDs independently of the
-// (mostly disarmed, immediately retiring) neighbouring slots; measured 97 -> 73 us at 65 536 envs
+// One wavefront per workgroup, launched in this order:
+//   [fill waves]  fill.n_fill_waves workgroups that only stream the LIDAR background (LIDARSpec.empty_sphere,
+//                 angle_grid.py:95-104: all ones) with 16-byte stores, no loads: they sit next to the flying
+//                 waves for the whole launch and keep HBM busy while the physics is latency-bound;
+//   [drone waves] wave = slot * (Npad/64) + chunk, SLOT-major: the always-armed slots (agent, allies, the first
+//                 invaders of the current round) reach the SIMDs first, the mostly disarmed slots retire after
+//                 one load.  Chunk-major order let ~6 000 disarmed waves take the issue slots first.
+// Measured on stage03, 65 536 envs (tools/k1_phase.py): chunk-major + per-wave fill 82-93 us; this order 5x-7x us.
 #ifndef TE_K1_BLOCK
 #define TE_K1_BLOCK 64
 #endif
@@ -38,30 +46,36 @@ namespace te {
 #else
 #define TE_K1_ATTR
 #endif
-// LIDAR background (LIDARSpec.empty_sphere, angle_grid.py:95-104: all ones) streamed by the sub-step
-// kernel's waves: each wave owns kFillQuads * 64 float4 of the [N,3,13,26] buffer.  The stores are issued
-// right after the armed flag is requested and drain while the wave flies its 16 sub-steps (or retires, for
-// a disarmed slot), so the 4 KB/env observation write rides on the latency-bound physics for free.
-struct FillJob { float* lidar; uint32_t total_quads; };
+// Background job of one launch.  Quads [0, first_quads) are written by the drone waves (one float4 per lane, see
+// the note on register allocation below); [first_quads, total_quads) by the fill waves, quads_per_fill_wave each.
+struct FillJob { float* lidar; uint32_t total_quads; uint32_t n_fill_waves; uint32_t quads_per_fill_wave; uint32_t fill_pos; };
 
-// KFILL = float4 stores per lane (0 = no fill in this launch).  It is a template constant so the wait
-// for the armed flag can be a counted s_waitcnt vmcnt(KFILL): on gfx950 loads and stores retire through one
-// in-order counter, and a run-time store count would force vmcnt(0), i.e. every wave would first wait for
-// its 6 KB of background stores to be acknowledged.
-template <int FAMILY, bool NOISE, int KFILL>
+template <int FAMILY, bool NOISE, bool FILL>
 __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params p, const float* __restrict__ actions, FillJob fill) {
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (unsigned)TE_K1_BLOCK + threadIdx.x) >> 6));
+  int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (unsigned)TE_K1_BLOCK + threadIdx.x) >> 6));
   const int lane = threadIdx.x & 63;
   const int D = p.D;
-  const int chunk = wave / D;
-  const int slot = wave - chunk * D;
-  if (chunk >= (p.Npad >> 6)) return;
+  const int nchunks = p.Npad >> 6;
+  const float4 ones = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+  float4* fill_dst = reinterpret_cast<float4*>(fill.lidar);
+  if (FILL) {
+    const int fw = wave - (int)fill.fill_pos;  // fill waves sit at launch positions [fill_pos, fill_pos + n_fill_waves)
+    if (fw >= 0 && fw < (int)fill.n_fill_waves) {
+      const uint32_t first = (uint32_t)(D * nchunks) * 64u;
+      uint32_t q = first + (uint32_t)fw * fill.quads_per_fill_wave + (uint32_t)lane;
+      const uint32_t end = min(first + ((uint32_t)fw + 1u) * fill.quads_per_fill_wave, fill.total_quads);
+      for (; q < end; q += 64u) fill_dst[q] = ones;
+      return;
+    }
+    if (fw >= 0) wave -= (int)fill.n_fill_waves;
+  }
+  const int slot = wave / nchunks;
+  const int chunk = wave - slot * nchunks;
+  if (slot >= D) return;
   const int env = chunk * 64 + lane;  // planes are padded to Npad: lanes beyond N still read in bounds
-  // 32-bit element index = plane * (D * Npad) + (slot * Npad + env): the plane term is wave-uniform (SGPR),
-  // so every access is "scalar base + one shared VGPR offset" and no 64-bit address pairs stay live
-  const SlotLane P{p.dstate, p.estate, (uint32_t)D * (uint32_t)p.Npad, (uint32_t)slot * (uint32_t)p.Npad + (uint32_t)env,
-                   (uint32_t)p.Npad, (uint32_t)env};
-  const int armed = P.i(TE_D_ARMED);
+  const SlotLane P(p.dstate, p.estate, (uint32_t)D, (uint32_t)p.Npad, (uint32_t)slot, (uint32_t)env,
+                   (uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)D * (uint32_t)p.Npad, (uint32_t)TE_ENV_WORDS * (uint32_t)p.Npad);
+  const int armed = P.li(TE_D_ARMED);
   const bool active = env < p.N && armed != 0;
   const te_config& c = p.cfg;
   const bool mode7 = (FAMILY == FAM_STAGE01) && slot == 2;
@@ -79,38 +93,27 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   if (active) {
     if (slot == 0) act = reinterpret_cast<const float4*>(actions)[env];
     else if (FAMILY == FAM_LEVEL4) {  // scripted drones: command prepared by the previous K2 / reset
-      cmd[0] = P.f(TE_X_CMD + 0); cmd[1] = P.f(TE_X_CMD + 1); cmd[3] = P.f(TE_X_CMD + 2);
-      if (slot >= c.n_pursuers) nav_next = P.i(TE_X_NAV_NEXT);
+      cmd[0] = P.lf(TE_X_CMD + 0); cmd[1] = P.lf(TE_X_CMD + 1); cmd[3] = P.lf(TE_X_CMD + 2);
+      if (slot >= c.n_pursuers) nav_next = P.li(TE_X_NAV_NEXT);
     } else {                          // stage01 / stage02: persistent set-points
 #pragma unroll
-      for (int k = 0; k < 4; ++k) cmd[k] = P.f(TE_D_SETPOINT + k);
+      for (int k = 0; k < 4; ++k) cmd[k] = P.lf(TE_D_SETPOINT + k);
     }
 #pragma unroll
-    for (int k = 0; k < 29; ++k) raw[k] = P.f(TE_D_POS + k);  // POS .. PID_ZV_E are words 0..28
+    for (int k = 0; k < 29; ++k) raw[k] = P.lf(TE_D_POS + k);  // POS .. PID_ZV_E are words 0..28
     if (mode7) {
-      pf = V3{P.f(TE_D_PENDING), P.f(TE_D_PENDING + 1), P.f(TE_D_PENDING + 2)};
-      pt = V3{P.f(TE_D_PENDING + 3), P.f(TE_D_PENDING + 4), P.f(TE_D_PENDING + 5)};
+      pf = V3{P.lf(TE_D_PENDING), P.lf(TE_D_PENDING + 1), P.lf(TE_D_PENDING + 2)};
+      pt = V3{P.lf(TE_D_PENDING + 3), P.lf(TE_D_PENDING + 4), P.lf(TE_D_PENDING + 5)};
     }
-    episode = (uint32_t)P.ei(TE_E_EPISODE);
+    episode = (uint32_t)P.lei(TE_E_EPISODE);
     // stage01 counts step_calls BEFORE the sim loop (pyflyt_level2_environment_modified_v2.py:128)
-    step_index = (uint32_t)P.ei(TE_E_STEP) + (FAMILY == FAM_STAGE01 ? 1u : 0u);
+    step_index = (uint32_t)P.lei(TE_E_STEP) + (FAMILY == FAM_STAGE01 ? 1u : 0u);
   }
-  // LIDAR background stores.  ONE store per lane goes here, between the load block and the divergent early
-  // exit: with hipcc (ROCm 7.2) that keeps the two regions apart and the kernel allocates 96 VGPRs
-  // (5 waves/SIMD, no spills) instead of 134 (3 waves/SIMD).  The other KFILL-1 are issued LAST by an armed
-  // lane, so they drain behind its own critical path (loads -> 16 sub-steps -> state stores), and right
-  // away by a lane that has no drone to fly.
-  constexpr int KFIRST = KFILL < 1 ? KFILL : 1;
-  const float4 ones = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-  float4* fill_dst = reinterpret_cast<float4*>(fill.lidar);
-  const uint32_t fill_q0 = (uint32_t)wave * (uint32_t)(KFILL * 64) + (uint32_t)lane, fill_last = fill.total_quads - 1u;
-#pragma unroll
-  for (int k = 0; k < KFIRST; ++k) fill_dst[min(fill_q0 + (uint32_t)(k * 64), fill_last)] = ones;  // clamped, never predicated
-  auto background = [&]() {
-#pragma unroll
-    for (int k = KFIRST; k < KFILL; ++k) fill_dst[min(fill_q0 + (uint32_t)(k * 64), fill_last)] = ones;
-  };
-  if (!active) { background(); return; }
+  // ONE background store per lane goes here, between the load block and the divergent early exit: with hipcc
+  // (ROCm 7.2) that keeps the two regions apart and the kernel allocates < 96 VGPRs (5 waves/SIMD, no spills)
+  // instead of ~130 (3 waves/SIMD).  It is clamped, never predicated.
+  if (FILL) fill_dst[min((uint32_t)wave * 64u + (uint32_t)lane, fill.total_quads - 1u)] = ones;
+  if (!active) return;
 
   // ---- set-point for this env.step
   float sp[4];
@@ -120,11 +123,11 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) sp[k] = cmd[k];
-    if (FAMILY == FAM_LEVEL4 && slot >= c.n_pursuers) P.i(TE_D_NAV_STATE) = nav_next;
+    if (FAMILY == FAM_LEVEL4 && slot >= c.n_pursuers) P.si(TE_D_NAV_STATE, nav_next);
   }
   if (slot == 0 || FAMILY == FAM_LEVEL4) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) P.f(TE_D_SETPOINT + k) = sp[k];
+    for (int k = 0; k < 4; ++k) P.sf(TE_D_SETPOINT + k, sp[k]);
   }
   Body b;
   b.pos = V3{raw[TE_D_POS], raw[TE_D_POS + 1], raw[TE_D_POS + 2]};
@@ -143,25 +146,28 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   // registers are not live (and conditionally written) across it.
   const int S = c.substeps;
   const Derived& kd = p.kd;
-  float nz[4] = {0, 0, 0, 0};
+  // One Philox call feeds two consecutive sub-steps: words {x,y} go to the even one, {z,w} wait in two
+  // registers for the odd one.
   const int n_plain = c.observe_lag ? S - 1 : S;
-  U4 bits{0, 0, 0, 0};
+  uint32_t na = 0, nb = 0, held_a = 0, held_b = 0;
+#define TE_DRAW(s_)                                                                   \
+  if (NOISE) {                                                                        \
+    if (((s_) & 1) == 0) {                                                            \
+      const U4 bits = motor_noise_bits(c, env, slot, episode, step_index, (s_));      \
+      na = bits.x; nb = bits.y; held_a = bits.z; held_b = bits.w;                     \
+    } else { na = held_a; nb = held_b; }                                              \
+  }
   for (int s = 0; s < n_plain; ++s) {
-    if (NOISE) {
-      if ((s & 1) == 0) bits = motor_noise_bits(c, env, slot, episode, step_index, s);  // one Philox per two sub-steps
-      motor_noise_from(bits, s, nz);
-    }
-    if (mode7) substep<true, false>(c, kd, b, sp, nz, pf, pt);  // wave-uniform: slot is per wave
-    else substep<false, false>(c, kd, b, sp, nz, pf, pt);
+    TE_DRAW(s)
+    if (mode7) substep<true, false, NOISE>(c, kd, b, sp, na, nb, pf, pt);  // wave-uniform: slot is per wave
+    else substep<false, false, NOISE>(c, kd, b, sp, na, nb, pf, pt);
   }
   if (c.observe_lag) {
-    if (NOISE) {
-      if (((S - 1) & 1) == 0) bits = motor_noise_bits(c, env, slot, episode, step_index, S - 1);
-      motor_noise_from(bits, S - 1, nz);
-    }
-    if (mode7) substep<true, true>(c, kd, b, sp, nz, pf, pt);
-    else substep<false, true>(c, kd, b, sp, nz, pf, pt);
+    TE_DRAW(S - 1)
+    if (mode7) substep<true, true, NOISE>(c, kd, b, sp, na, nb, pf, pt);
+    else substep<false, true, NOISE>(c, kd, b, sp, na, nb, pf, pt);
   }
+#undef TE_DRAW
 
   // ---- store
   const M3 R = rotation(b.q);
@@ -169,26 +175,25 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
     b.o_pos = b.pos; b.o_vel = mulT(R, b.vel); b.o_rate = b.wb; b.o_eul = euler_of(b.q);
   }
   const V3 ww = mul(R, b.wb);
-  P.f(TE_D_POS) = b.pos.x; P.f(TE_D_POS + 1) = b.pos.y; P.f(TE_D_POS + 2) = b.pos.z;
-  P.f(TE_D_QUAT) = b.q.x; P.f(TE_D_QUAT + 1) = b.q.y; P.f(TE_D_QUAT + 2) = b.q.z; P.f(TE_D_QUAT + 3) = b.q.w;
-  P.f(TE_D_VEL) = b.vel.x; P.f(TE_D_VEL + 1) = b.vel.y; P.f(TE_D_VEL + 2) = b.vel.z;
-  P.f(TE_D_OMEGA) = ww.x; P.f(TE_D_OMEGA + 1) = ww.y; P.f(TE_D_OMEGA + 2) = ww.z;
+  P.sf(TE_D_POS, b.pos.x); P.sf(TE_D_POS + 1, b.pos.y); P.sf(TE_D_POS + 2, b.pos.z);
+  P.sf(TE_D_QUAT, b.q.x); P.sf(TE_D_QUAT + 1, b.q.y); P.sf(TE_D_QUAT + 2, b.q.z); P.sf(TE_D_QUAT + 3, b.q.w);
+  P.sf(TE_D_VEL, b.vel.x); P.sf(TE_D_VEL + 1, b.vel.y); P.sf(TE_D_VEL + 2, b.vel.z);
+  P.sf(TE_D_OMEGA, ww.x); P.sf(TE_D_OMEGA + 1, ww.y); P.sf(TE_D_OMEGA + 2, ww.z);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) P.f(TE_D_THROTTLE + k) = b.thr[k];
+  for (int k = 0; k < 4; ++k) P.sf(TE_D_THROTTLE + k, b.thr[k]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { P.f(TE_D_PID_AV_I + k) = b.av_i[k]; P.f(TE_D_PID_AV_E + k) = b.av_e[k]; }
+  for (int k = 0; k < 3; ++k) { P.sf(TE_D_PID_AV_I + k, b.av_i[k]); P.sf(TE_D_PID_AV_E + k, b.av_e[k]); }
 #pragma unroll
-  for (int k = 0; k < 2; ++k) { P.f(TE_D_PID_LV_I + k) = b.lv_i[k]; P.f(TE_D_PID_LV_E + k) = b.lv_e[k]; }
-  P.f(TE_D_PID_ZV_I) = b.zv_i; P.f(TE_D_PID_ZV_E) = b.zv_e;
-  P.f(TE_D_OBS_POS) = b.o_pos.x; P.f(TE_D_OBS_POS + 1) = b.o_pos.y; P.f(TE_D_OBS_POS + 2) = b.o_pos.z;
-  P.f(TE_D_OBS_EULER) = b.o_eul.x; P.f(TE_D_OBS_EULER + 1) = b.o_eul.y; P.f(TE_D_OBS_EULER + 2) = b.o_eul.z;
-  P.f(TE_D_OBS_VEL) = b.o_vel.x; P.f(TE_D_OBS_VEL + 1) = b.o_vel.y; P.f(TE_D_OBS_VEL + 2) = b.o_vel.z;
-  P.f(TE_D_OBS_RATE) = b.o_rate.x; P.f(TE_D_OBS_RATE + 1) = b.o_rate.y; P.f(TE_D_OBS_RATE + 2) = b.o_rate.z;
+  for (int k = 0; k < 2; ++k) { P.sf(TE_D_PID_LV_I + k, b.lv_i[k]); P.sf(TE_D_PID_LV_E + k, b.lv_e[k]); }
+  P.sf(TE_D_PID_ZV_I, b.zv_i); P.sf(TE_D_PID_ZV_E, b.zv_e);
+  P.sf(TE_D_OBS_POS, b.o_pos.x); P.sf(TE_D_OBS_POS + 1, b.o_pos.y); P.sf(TE_D_OBS_POS + 2, b.o_pos.z);
+  P.sf(TE_D_OBS_EULER, b.o_eul.x); P.sf(TE_D_OBS_EULER + 1, b.o_eul.y); P.sf(TE_D_OBS_EULER + 2, b.o_eul.z);
+  P.sf(TE_D_OBS_VEL, b.o_vel.x); P.sf(TE_D_OBS_VEL + 1, b.o_vel.y); P.sf(TE_D_OBS_VEL + 2, b.o_vel.z);
+  P.sf(TE_D_OBS_RATE, b.o_rate.x); P.sf(TE_D_OBS_RATE + 1, b.o_rate.y); P.sf(TE_D_OBS_RATE + 2, b.o_rate.z);
   if (mode7) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) P.f(TE_D_PENDING + k) = 0.0f;
+    for (int k = 0; k < 6; ++k) P.sf(TE_D_PENDING + k, 0.0f);
   }
-  background();
 }
 
 // ============================================================================================
@@ -387,6 +392,8 @@ struct te_env {
   int device;
   int family;
   size_t lds_bytes;
+  int n_fill_waves = 256;  // fill waves of the sub-step kernel (one per CU of an MI355X); TE_FILL_WAVES overrides
+  int fill_pos_pct = 0;    // where they sit among the drone waves, in % of the launch (TE_FILL_POS)
   // profiling (te_profile_begin / te_profile_end)
   std::vector<hipEvent_t> events;
   int prof_cap = 0, prof_used = 0;
@@ -448,6 +455,8 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   e->p.kd = derive(*cfg);
   e->p.N = cfg->n_envs; e->p.D = D; e->p.Npad = (cfg->n_envs + 63) / 64 * 64;
   e->lds_bytes = (size_t)lds_rows(D, cfg->n_pursuers) * kEPB * sizeof(uint32_t);
+  if (const char* v = getenv("TE_FILL_POS")) { int n = atoi(v); if (n >= 0 && n <= 100) e->fill_pos_pct = n; }
+  if (const char* v = getenv("TE_FILL_WAVES")) { int n = atoi(v); if (n >= 1 && n <= (1 << 20)) e->n_fill_waves = n; }
   {
     hipError_t le = hipSuccess;
     launch_by_family(e->family, [&](auto fam) {
@@ -530,41 +539,31 @@ __attribute__((visibility("default"))) int te_step(te_env* e, const float* actio
   const bool prof = e->prof_used + 3 <= e->prof_cap;
   if (prof) TE_HIP(hipEventRecord(e->events[e->prof_used + 0], st));
   const int waves = p.D * (p.Npad >> 6);
-  constexpr int wpb = TE_K1_BLOCK / 64;
-  const int b1 = (waves + wpb - 1) / wpb;
   const bool noise = p.cfg.motor_noise != 0;
-  // LIDAR background: N*1014 floats = quads float4 (+ <4 tail floats).  Each wave streams KFILL*64 float4.
-  FillJob fill{nullptr, 0u};
-  int kfill = 0;
+  // LIDAR background: N*1014 floats = quads float4 (+ <4 tail floats).  The drone waves write one float4 per
+  // lane; the rest is split evenly over the fill waves.
+  FillJob fill{nullptr, 0u, 0u, 0u, 0u};
   const size_t n_floats = (size_t)p.N * TE_OBS_LIDAR_WORDS;
   if (obs_lidar) {
-    const size_t quads = n_floats >> 2;
-    const size_t need = (quads + (size_t)waves * 64 - 1) / ((size_t)waves * 64);  // float4 per lane
-    for (int k : {24, 26, 37}) if (kfill == 0 && need <= (size_t)k) kfill = k;
-    if (kfill && quads < (1ull << 32) && quads > 0) {
-      fill = FillJob{obs_lidar, (uint32_t)quads};
-#ifdef TE_DEBUG_FILL_CLAMP
-      fill.total_quads = 1u;  // experiment: every background store hits one quad (no HBM stream)
-#endif
+    const size_t quads = n_floats >> 2, first = (size_t)waves * 64;
+    if (quads > first && quads < (1ull << 32)) {
+      const uint32_t nf = (uint32_t)e->n_fill_waves;
+      const uint32_t per = (uint32_t)((((quads - first) + nf - 1) / nf + 63) / 64 * 64);
+      fill = FillJob{obs_lidar, (uint32_t)quads, nf, per, (uint32_t)((long long)waves * e->fill_pos_pct / 100)};
       if (n_floats & 3) hipLaunchKernelGGL(fill_ones_kernel, dim3(1), dim3(64), 0, st, obs_lidar + (quads << 2), n_floats & 3);
-    } else {  // shapes the in-kernel fill does not cover (e.g. 3 drones per env): plain fill kernel first
-      kfill = 0;
+    } else {  // tiny or huge buffers: plain fill kernel first
       hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, obs_lidar, n_floats);
     }
   }
+  const int b1 = (int)fill.n_fill_waves + waves;
   launch_by_family(e->family, [&](auto fam) {
     constexpr int F = decltype(fam)::value;
-    auto go = [&](auto kf) {
-      constexpr int K = decltype(kf)::value;
-      if (noise) hipLaunchKernelGGL((substeps_kernel<F, true, K>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p, actions, fill);
-      else hipLaunchKernelGGL((substeps_kernel<F, false, K>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p, actions, fill);
+    auto go = [&](auto noise_c, auto fill_c) {
+      hipLaunchKernelGGL((substeps_kernel<F, decltype(noise_c)::value, decltype(fill_c)::value>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p,
+                         actions, fill);
     };
-    switch (kfill) {
-      case 24: go(std::integral_constant<int, 24>{}); break;
-      case 26: go(std::integral_constant<int, 26>{}); break;
-      case 37: go(std::integral_constant<int, 37>{}); break;
-      default: go(std::integral_constant<int, 0>{}); break;
-    }
+    if (noise) { if (fill.lidar) go(std::true_type{}, std::true_type{}); else go(std::true_type{}, std::false_type{}); }
+    else { if (fill.lidar) go(std::false_type{}, std::true_type{}); else go(std::false_type{}, std::false_type{}); }
   });
   if (prof) TE_HIP(hipEventRecord(e->events[e->prof_used + 1], st));
   const int b2 = (p.N + kEPB - 1) / kEPB;

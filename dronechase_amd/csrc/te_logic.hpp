@@ -390,12 +390,13 @@ template <class V> TE_DEV void stage01_replace_invader(const te_config& c, const
 #pragma unroll
   for (int k = 0; k < 2; ++k) { b.lv_i[k] = v.gf(TE_D_PID_LV_I + k, s); b.lv_e[k] = v.gf(TE_D_PID_LV_E + k, s); }
   b.zv_i = v.gf(TE_D_PID_ZV_I, s); b.zv_e = v.gf(TE_D_PID_ZV_E, s);
-  float nz[4] = {0, 0, 0, 0};
-  if (c.motor_noise) motor_noise(c, v.env, s, episode, step_index, 255, nz);
   // controller + motors only: the body must not move, so evaluate the wrench by differencing a
   // throw-away sub-step from rest (velocity change * mass / dt = applied force, etc.)
   V3 pf{0, 0, 0}, pt{0, 0, 0};
-  substep<true, false>(c, derive(c), b, sp, nz, pf, pt);
+  if (c.motor_noise) {  // sub-step index 255: Philox call 127, words {z, w}
+    const U4 bits = motor_noise_bits(c, v.env, s, episode, step_index, 255);
+    substep<true, false, true>(c, derive(c), b, sp, bits.z, bits.w, pf, pt);
+  } else substep<true, false, false>(c, derive(c), b, sp, 0u, 0u, pf, pt);
   const float dt = c.physics_dt;
   V3 F{b.vel.x * c.quad.mass / dt, b.vel.y * c.quad.mass / dt, (b.vel.z / dt + c.quad.gravity) * c.quad.mass};
   V3 Tq{b.wb.x * c.quad.inertia[0] / dt, b.wb.y * c.quad.inertia[1] / dt, b.wb.z * c.quad.inertia[2] / dt};
