@@ -17,9 +17,8 @@
 namespace te {
 
 // extra per-drone planes that are not part of the public state blob
-enum { TE_X_CMD = TE_DRONE_WORDS, /* 3: next scripted velocity command vx,vy,vz */
-       TE_X_NAV_NEXT = TE_DRONE_WORDS + 3, /* i32: FSM state after the pending update */
-       TE_X_WORDS = 4 };
+enum { TE_X_CMD = TE_DRONE_WORDS, /* 3: velocity command vx,vy,vz of a scripted ALLY for the next step */
+       TE_X_WORDS = 3 };
 
 // constants of the sub-step loop derived from te_config.  Computed ONCE on the host (te_create) and passed
 // by value in the kernel arguments, so they live in SGPRs: gfx950 has no scalar float ALU, and deriving
@@ -39,10 +38,21 @@ struct Params {
 #ifdef TE_DEBUG_STAMPS
 #define TE_STAMP(p, blk, idx)                                                                     \
   do {                                                                                            \
-    if ((p).dbg && blockIdx.x == (blk) && threadIdx.x == 0) (p).dbg[(idx)] = __builtin_amdgcn_s_memrealtime(); \
+    if ((p).dbg && threadIdx.x == 0) {                                                            \
+      const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                             \
+      if (blockIdx.x == (blk)) (p).dbg[(idx)] = t_;                                               \
+      (p).dbg[64 + blockIdx.x * 16 + (idx)] = t_; /* every block: tools/k2_blocks.py */            \
+    }                                                                                             \
+  } while (0)
+// finer stamps from inside the per-env logic (lane 0 of wave 0 of every block), slots 8..15 of the block's record
+__device__ unsigned long long* g_te_dbg = nullptr;
+#define TE_LSTAMP(idx)                                                                            \
+  do {                                                                                            \
+    if (g_te_dbg && threadIdx.x == 0) g_te_dbg[64 + blockIdx.x * 16 + (idx)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define TE_STAMP(p, blk, idx) do {} while (0)
+#define TE_LSTAMP(idx) do {} while (0)
 #endif
 
 #define TE_DEV __device__ __forceinline__
@@ -75,6 +85,10 @@ struct SlotLane {
   TE_DEV int32_t li(int w) const { return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(d, (int)off_bytes, (int)((uint32_t)w * plane_bytes), 0); }
   TE_DEV void sf(int w, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), d, (int)off_bytes, (int)((uint32_t)w * plane_bytes), 0); }
   TE_DEV void si(int w, int32_t v) const { __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, d, (int)off_bytes, (int)((uint32_t)w * plane_bytes), 0); }
+  // word w of ANOTHER slot of this lane's env (cross-drone reads of the scripted navigators)
+  TE_DEV float lf_slot(int w, int s) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d, (int)env_bytes, (int)((uint32_t)w * plane_bytes + (uint32_t)s * eplane_bytes), 0));
+  }
   TE_DEV int32_t lei(int w) const { return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(e, (int)env_bytes, (int)((uint32_t)w * eplane_bytes), 0); }
 };
 

@@ -50,6 +50,12 @@ namespace te {
 // the note on register allocation below); [first_quads, total_quads) by the fill waves, quads_per_fill_wave each.
 struct FillJob { float* lidar; uint32_t total_quads; uint32_t n_fill_waves; uint32_t quads_per_fill_wave; uint32_t fill_pos; };
 
+// what kamikaze_update() reads of the other drones, through the wave's buffer resource
+struct NavView {
+  const SlotLane& P; int Pn;
+  TE_DEV float gf(int w, int s) const { return P.lf_slot(w, s); }
+};
+
 template <int FAMILY, bool NOISE, bool FILL>
 __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params p, const float* __restrict__ actions, FillJob fill) {
   int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (unsigned)TE_K1_BLOCK + threadIdx.x) >> 6));
@@ -92,9 +98,17 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   uint32_t episode = 0, step_index = 0;
   if (active) {
     if (slot == 0) act = reinterpret_cast<const float4*>(actions)[env];
-    else if (FAMILY == FAM_LEVEL4) {  // scripted drones: command prepared by the previous K2 / reset
-      cmd[0] = P.lf(TE_X_CMD + 0); cmd[1] = P.lf(TE_X_CMD + 1); cmd[3] = P.lf(TE_X_CMD + 2);
-      if (slot >= c.n_pursuers) nav_next = P.li(TE_X_NAV_NEXT);
+    else if (FAMILY == FAM_LEVEL4) {
+      if (slot < c.n_pursuers) {  // ally: command prepared by the previous engage/observe launch (or reset)
+        cmd[0] = P.lf(TE_X_CMD + 0); cmd[1] = P.lf(TE_X_CMD + 1); cmd[3] = P.lf(TE_X_CMD + 2);
+      } else {                    // invader: KamikazeNavigator.update from the pursuers' last IMU positions
+        const NavView nv{P, c.n_pursuers};
+        const uint32_t S = (uint32_t)P.lei(TE_E_SNAP_MASK);
+        const V3 me{P.lf(TE_D_OBS_POS), P.lf(TE_D_OBS_POS + 1), P.lf(TE_D_OBS_POS + 2)};
+        float out[3];
+        nav_next = kamikaze_update(c, nv, S, P.li(TE_D_NAV_STATE), me, out);
+        cmd[0] = out[0]; cmd[1] = out[1]; cmd[3] = out[2];
+      }
     } else {                          // stage01 / stage02: persistent set-points
 #pragma unroll
       for (int k = 0; k < 4; ++k) cmd[k] = P.lf(TE_D_SETPOINT + k);
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
   // The [N,3,13,26] LIDAR buffer has already been filled with ones by the sub-step kernel's waves
   // (FillJob): only the hit cells are patched here.
   TE_STAMP(p, 500, 0);
+  if (threadIdx.x < kEPB) sm[r.task() * kEPB + threadIdx.x] = 0u;
   stage_block(p, sm, r, env0);
   __syncthreads();
   TE_STAMP(p, 500, 1);
@@ -276,11 +291,26 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
   __syncthreads();
   TE_STAMP(p, 500, 4);
   if (FAMILY == FAM_LEVEL4) {
-    // epilogue split by wave: wave 0 writes the inertial / last_action rows while waves 1..3 prepare the scripted
-    // commands of the next step, one (env, drone) item per thread iteration
-    if (threadIdx.x < 64) emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, 64);
+    // spawn phase: the slots of every env that starts a new round or auto-resets, one (env, slot) per thread
+    // iteration (slot-major: consecutive threads = consecutive envs).  Rare per env, but with 64 envs per
+    // block some block needs it almost every step, and left to the env's own lane it doubles that block's
+    // critical path (D Philox draws + trigonometry + ~40 stores each, serially).
+    const uint32_t my_task = threadIdx.x < kEPB ? sm[r.task() * kEPB + threadIdx.x] : 0u;
+    if (__syncthreads_or(my_task != 0u)) {
+      for (int it = threadIdx.x; it < kEPB * p.D; it += blockDim.x) {
+        const int l = it & (kEPB - 1), s = it / kEPB;
+        const uint32_t t = sm[r.task() * kEPB + l];
+        if (t == 0u || l >= nvalid) continue;
+        SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + l, r.P}, sm, l, r, p.D, r.P, env0 + l, false};
+        level4_spawn_slot(p.cfg, v, s, (int)(t & 0xFFu), (uint32_t)v.egi(TE_E_EPISODE), (t >> 8) != 0u);
+      }
+      __syncthreads();
+    }
+    // epilogue split by wave: wave 3 prepares the allies' commands of the next step, one (env, ally) item per
+    // thread iteration, while waves 0..2 write the inertial / last_action rows
+    if (threadIdx.x < 192) emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, 192);
     else
-      for (int it = threadIdx.x - 64; it < kEPB * (p.D - 1); it += blockDim.x - 64) {
+      for (int it = threadIdx.x - 192; it < kEPB * (r.P - 1); it += 64) {
         const int l = it & (kEPB - 1), s = 1 + it / kEPB;
         if (l >= nvalid) continue;
         SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + l, r.P}, sm, l, r, p.D, r.P, env0 + l, sm[r.prevalid() * kEPB + l] != 0u};
@@ -476,8 +506,9 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   }
   e->p.dbg = nullptr;
 #ifdef TE_DEBUG_STAMPS
-  if (hipMalloc(&e->p.dbg, 64 * sizeof(unsigned long long)) != hipSuccess) e->p.dbg = nullptr;
-  else (void)hipMemset(e->p.dbg, 0, 64 * sizeof(unsigned long long));
+  const size_t dbg_words = 64 + 16 * (size_t)(e->p.Npad / kEPB + 1);
+  if (hipMalloc(&e->p.dbg, dbg_words * sizeof(unsigned long long)) != hipSuccess) e->p.dbg = nullptr;
+  else { (void)hipMemset(e->p.dbg, 0, dbg_words * sizeof(unsigned long long)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_te_dbg), &e->p.dbg, sizeof(e->p.dbg)); }
 #endif
   TE_HIP(hipMemsetAsync(e->p.dstate, 0, dwords * 4, nullptr));
   TE_HIP(hipMemsetAsync(e->p.estate, 0, ewords * 4, nullptr));
@@ -650,7 +681,7 @@ __attribute__((visibility("default"))) int te_profile_end(te_env* e, float* subs
 // Diagnostic builds (-DTE_DEBUG_STAMPS): s_memrealtime (100 MHz) stamps one workgroup wrote at its phase
 // boundaries during the last launch; all zeros in a normal build.
 __attribute__((visibility("default"))) int te_debug_stamps(te_env* e, uint64_t* out_host, int32_t n) {
-  if (!e || !out_host || n < 1 || n > 64) return fail("te_debug_stamps: bad argument");
+  if (!e || !out_host || n < 1 || (size_t)n > 64 + 16 * (size_t)(e->p.Npad / kEPB + 1)) return fail("te_debug_stamps: bad argument");
   memset(out_host, 0, (size_t)n * sizeof(uint64_t));
   if (!e->p.dbg) return 0;
   DeviceGuard guard(e->device);

@@ -51,9 +51,10 @@ struct Rows {
   TE_DEV int hitmask() const { return lrhat() + D; }        // 1   : bit j = drone j owns its cell in this step's sphere
   TE_DEV int done() const { return hitmask() + 1; }         // 1   : env auto-reset this step
   TE_DEV int prevalid() const { return done() + 1; }        // 1   : distance / zone rows still valid after the logic
-  TE_DEV int total() const { return prevalid() + 1; }
+  TE_DEV int task() const { return prevalid() + 1; }        // 1   : level4 spawn work left to the block: round | reset << 8
+  TE_DEV int total() const { return task() + 1; }
 };
-__host__ __device__ inline int lds_rows(int D, int P) { return 9 * D + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 5; }
+__host__ __device__ inline int lds_rows(int D, int P) { return 9 * D + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 6; }
 
 struct SView {
   GView g; uint32_t* sm; int lane; Rows r;
@@ -218,16 +219,14 @@ template <class V> TE_DEV int closest_ally(const V& v, uint32_t mask, int p) {
 
 // ------------------------------------------------------------------------------------------------
 // scripted commands of the NEXT step (Task.on_step_start, exp03_vFinal_task.py:232-244,276-283).
-// They depend only on the state at the end of this step, so they are prepared here and consumed by the
-// sub-step kernel (which then needs no cross-drone reads).
+// They depend only on the state at the end of this step.  The allies' are prepared here (engage/observe kernel)
+// and read back by the sub-step kernel; each invader works its own out at the top of the sub-step kernel.
 // ------------------------------------------------------------------------------------------------
-template <class V> TE_DEV void set_cmd_toward(const V& v, int s, V3 from, V3 to, float speed) {
+TE_DEV void cmd_toward(V3 from, V3 to, float speed, float out[3]) {
   V3 d = sub(to, from);
   float n = norm(d);
   float inv = n > 0.0f ? 1.0f / n : 1.0f;  // zero vector stays zero (…air_combat_only.py:191-195)
-  float vx, vy, vz;
-  command_to_velocity(d.x * inv, d.y * inv, d.z * inv, speed, vx, vy, vz);
-  v.sf(TE_X_CMD + 0, s, vx); v.sf(TE_X_CMD + 1, s, vy); v.sf(TE_X_CMD + 2, s, vz);
+  command_to_velocity(d.x * inv, d.y * inv, d.z * inv, speed, out[0], out[1], out[2]);
 }
 // GeometryUtils.is_point_inside_cone (geometry_utils.py:6-29)
 TE_DEV bool inside_cone(V3 p, V3 apex, V3 base, float degrees) {
@@ -237,86 +236,114 @@ TE_DEV bool inside_cone(V3 p, V3 apex, V3 base, float degrees) {
   float cosang = (ap.x * ab.x + ap.y * ab.y + ap.z * ab.z) / (nap * nab);
   return acosf(cosang) * (180.0f / kPi) <= 0.5f * degrees;
 }
-template <class V> TE_DEV bool building_path_clear(const te_config& c, const V& v, uint32_t mask, int s, float degrees) {
+template <class V> TE_DEV bool building_path_clear(const te_config& c, const V& v, uint32_t mask, V3 me, float degrees) {
   if (!c.kamikaze_cone_check) return false;  // …air_combat_only.py:83-96: constant False
   V3 b{c.building_position[0], c.building_position[1], c.building_position[2]};
-  V3 me = obs_pos(v, s);
   for (int p = 0; p < c.n_pursuers; ++p)
     if (((mask >> p) & 1u) && inside_cone(obs_pos(v, p), me, b, degrees)) return false;
   return true;
 }
-// command of ONE scripted drone `s` (invader: KamikazeNavigator.update; ally: LoyalWingmanBehaviorTree.update)
+// KamikazeNavigator.update of invader `s` (…air_combat_only.py:68-78): the transition is registered, the OLD
+// state executes.  Pure: reads the snapshot mask S, the invader's FSM state and IMU position `me`, and the
+// pursuers' IMU positions through `v`; returns the velocity command and the next FSM state.  Evaluated by the
+// invader's own wave at the top of the sub-step kernel (Task.on_step_start, exp03_vFinal_task.py:276-283).
+template <class V> TE_DEV int kamikaze_update(const te_config& c, const V& v, uint32_t S, int state, V3 me, float out[3]) {
+  const int Pn = c.n_pursuers;
+  const uint32_t pursuer_bits = S & ((1u << Pn) - 1u);
+  int next = state;
+  if (state == TE_NAV_WAIT) {
+    if (building_path_clear(c, v, S, me, 60.0f)) next = TE_NAV_COLLIDE_BUILDING;
+    else if (pursuer_bits) next = TE_NAV_COLLIDE_WINGMAN;
+    out[0] = out[1] = out[2] = 0.0f;  // hover (:163)
+  } else if (state == TE_NAV_COLLIDE_WINGMAN) {
+    if (!pursuer_bits) next = TE_NAV_COLLIDE_BUILDING;
+    // identify_closest_pursuer (offsets_handler.py:228-254) from the IMU positions
+    int best = -1; float bd = 0.0f; V3 target{0, 0, 0};
+    for (int p = 0; p < Pn; ++p) {
+      if (!((S >> p) & 1u)) continue;
+      const V3 pp = obs_pos(v, p);
+      const float d = dist(pp, me);
+      if (best < 0 || d < bd) { best = p; bd = d; target = pp; }
+    }
+    cmd_toward(me, target, c.invader_speed, out);
+  } else {
+    if (!building_path_clear(c, v, S, me, 45.0f)) next = TE_NAV_COLLIDE_WINGMAN;
+    cmd_toward(me, V3{c.building_position[0], c.building_position[1], c.building_position[2]}, c.invader_speed, out);
+  }
+  return next;
+}
+// command of ONE scripted ally `s` for the NEXT step (LoyalWingmanBehaviorTree.update), stored in the TE_X_CMD
+// planes by the engage/observe kernel, where the pursuer-invader distances are at hand in LDS
 template <class V> TE_DEV void prepare_slot(const te_config& c, const V& v, int s) {
   const int Pn = c.n_pursuers;
-  if (!v.gi(TE_D_ARMED, s)) return;
+  if (s == 0 || s >= Pn || !v.gi(TE_D_ARMED, s)) return;
   const uint32_t S = (uint32_t)v.egi(TE_E_SNAP_MASK);
-  if (s >= Pn) {  // KamikazeNavigator.update (…air_combat_only.py:68-78): transition registered, OLD state executes
-    const uint32_t pursuer_bits = S & ((1u << Pn) - 1u);
-    int state = v.gi(TE_D_NAV_STATE, s), next = state;
-    V3 me = obs_pos(v, s);
-    if (state == TE_NAV_WAIT) {
-      if (building_path_clear(c, v, S, s, 60.0f)) next = TE_NAV_COLLIDE_BUILDING;
-      else if (pursuer_bits) next = TE_NAV_COLLIDE_WINGMAN;
-      v.sf(TE_X_CMD + 0, s, 0.0f); v.sf(TE_X_CMD + 1, s, 0.0f); v.sf(TE_X_CMD + 2, s, 0.0f);  // hover (:163)
-    } else if (state == TE_NAV_COLLIDE_WINGMAN) {
-      if (!pursuer_bits) next = TE_NAV_COLLIDE_BUILDING;
-      int t = closest_pursuer(v, S, s);
-      V3 target = t >= 0 ? obs_pos(v, t) : V3{0, 0, 0};
-      set_cmd_toward(v, s, me, target, c.invader_speed);
-    } else {
-      if (!building_path_clear(c, v, S, s, 45.0f)) next = TE_NAV_COLLIDE_WINGMAN;
-      set_cmd_toward(v, s, me, V3{c.building_position[0], c.building_position[1], c.building_position[2]}, c.invader_speed);
-    }
-    v.si(TE_X_NAV_NEXT, s, next);
-    return;
-  }
   // drive_loyalwingmen: get_armed_pursuers()[1:] (exp03_vFinal_task.py:238-244): with the agent dead the
   // first armed ally is the one that is skipped
-  if (s == 0) return;
   if (!v.gi(TE_D_ARMED, 0)) {
     int first = -1;
     for (int a = 1; a < Pn; ++a) if (v.gi(TE_D_ARMED, a)) { first = a; break; }
     if (s == first) return;
   }
+  float out[3] = {0.0f, 0.0f, 0.0f};
   if (c.ally_policy == TE_ALLY_BT) {  // LoyalWingmanBehaviorTree (loyalwingman_navigator.py:238-352)
     V3 me = obs_pos(v, s);
     if (gun_available(c, v.gi(TE_D_MUNITION, s), v.gi(TE_D_LAST_FIRED, s), v.egi(TE_E_STEP))) {
       float dm;
       int t = ((S >> s) & 1u) ? closest_invader(v, S, s, dm) : -1;
       V3 target = t >= 0 ? obs_pos(v, t) : V3{0, 0, 0};
-      set_cmd_toward(v, s, me, target, c.ally_speed);
+      cmd_toward(me, target, c.ally_speed, out);
     } else {
-      set_cmd_toward(v, s, me, V3{v.gf(TE_D_FORMATION, s), v.gf(TE_D_FORMATION + 1, s), v.gf(TE_D_FORMATION + 2, s)}, c.ally_speed);
+      cmd_toward(me, V3{v.gf(TE_D_FORMATION, s), v.gf(TE_D_FORMATION + 1, s), v.gf(TE_D_FORMATION + 2, s)}, c.ally_speed, out);
     }
-  } else if (c.ally_policy == TE_ALLY_FROZEN) {  // exp04_vFinal_task.py:240-242: drive([0,0,0,1])
-    v.sf(TE_X_CMD + 0, s, 0.0f); v.sf(TE_X_CMD + 1, s, 0.0f); v.sf(TE_X_CMD + 2, s, 0.0f);
-  } else {
-    v.sf(TE_X_CMD + 0, s, v.gf(TE_D_SETPOINT + 0, s)); v.sf(TE_X_CMD + 1, s, v.gf(TE_D_SETPOINT + 1, s));
-    v.sf(TE_X_CMD + 2, s, v.gf(TE_D_SETPOINT + 3, s));
+  } else if (c.ally_policy != TE_ALLY_FROZEN) {  // (frozen: exp04_vFinal_task.py:240-242: drive([0,0,0,1]))
+    out[0] = v.gf(TE_D_SETPOINT + 0, s); out[1] = v.gf(TE_D_SETPOINT + 1, s); out[2] = v.gf(TE_D_SETPOINT + 3, s);
   }
+  v.sf(TE_X_CMD + 0, s, out[0]); v.sf(TE_X_CMD + 1, s, out[1]); v.sf(TE_X_CMD + 2, s, out[2]);
 }
 template <class V> TE_DEV void prepare_level4_commands(const te_config& c, const V& v) {
-  for (int s = 1; s < v.D; ++s) prepare_slot(c, v, s);
+  for (int s = 1; s < c.n_pursuers; ++s) prepare_slot(c, v, s);
 }
 
 // ------------------------------------------------------------------------------------------------
 // resets
 // ------------------------------------------------------------------------------------------------
-// Task.setup_round (exp03_vFinal_task.py:180-196)
-template <class V> TE_DEV void level4_setup_round(const te_config& c, const V& v, int round, uint32_t episode) {
+// Task.setup_round (exp03_vFinal_task.py:180-196) and Task.on_reset (:255-274), as ONE function per drone slot so
+// that the engage/observe kernel can hand the slots of a respawning env to the threads of its block (spawn
+// phase) instead of leaving all D of them to the env's own logic lane.  The draws are keyed on (slot, episode,
+// round), so the order in which slots are processed does not matter.
+//   invader slot: disarm; the first min(round, n_invaders) slots respawn armed on the born sphere
+//   pursuer slot: untouched by a new round; on reset, disarm + respawn armed on the pursuer sphere
+//   every slot  : navigator reset (OffsetHandler snapshot refresh + navigators reset())
+template <class V> TE_DEV void level4_spawn_slot(const te_config& c, const V& v, int s, int round, uint32_t episode, bool reset) {
   const int Pn = c.n_pursuers;
-  for (int j = Pn; j < v.D; ++j) disarm(v, j);
-  for (int i = 0; i < round && i < c.n_invaders; ++i) {
-    U4 r = env_rng(c, v.env, RNG_SPAWN_INVADER, (uint32_t)(Pn + i), 0, episode, (uint32_t)round);
-    respawn_armed(c, v, Pn + i, level4_position(c, c.born_radius, u01(r.x), u01(r.y)));
+  if (s >= Pn) {
+    disarm(v, s);
+    const int i = s - Pn;
+    if (i < round && i < c.n_invaders) {
+      U4 r = env_rng(c, v.env, RNG_SPAWN_INVADER, (uint32_t)s, 0, episode, (uint32_t)round);
+      respawn_armed(c, v, s, level4_position(c, c.born_radius, u01(r.x), u01(r.y)));
+    }
+  } else if (reset) {
+    U4 r = env_rng(c, v.env, RNG_SPAWN_PURSUER, (uint32_t)s, 0, episode, 0);
+    respawn_armed(c, v, s, level4_position(c, c.pursuer_spawn_radius, u01(r.x), u01(r.y)));
   }
+  v.si(TE_D_NAV_STATE, s, TE_NAV_WAIT);
 }
-template <class V> TE_DEV void level4_refresh_snapshot(const V& v) {
-  v.esi(TE_E_SNAP_MASK, (int)armed_mask(v));
-  for (int s = 0; s < v.D; ++s) v.si(TE_D_NAV_STATE, s, TE_NAV_WAIT);  // navigators reset()
+// armed mask once every slot has been through level4_spawn_slot
+template <class V> TE_DEV uint32_t level4_mask_after_spawn(const te_config& c, const V& v, int round, bool reset) {
+  const int Pn = c.n_pursuers;
+  uint32_t m = 0;
+  for (int p = 0; p < Pn; ++p) m |= ((reset || v.gi(TE_D_ARMED, p)) ? 1u : 0u) << p;
+  const int n = round < c.n_invaders ? round : c.n_invaders;
+  return m | (((1u << n) - 1u) << Pn);
 }
-// Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146, exp03_vFinal_task.py:255-274)
-template <class V> TE_DEV void level4_reset_env(const te_config& c, const V& v, bool prepare = true) {
+template <class V> TE_DEV void level4_setup_round(const te_config& c, const V& v, int round, uint32_t episode) {
+  for (int s = 0; s < v.D; ++s) level4_spawn_slot(c, v, s, round, episode, false);
+  v.esi(TE_E_SNAP_MASK, (int)level4_mask_after_spawn(c, v, round, false));
+}
+// the env-record half of Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146)
+template <class V> TE_DEV uint32_t level4_reset_record(const te_config& c, const V& v) {
   const uint32_t episode = (uint32_t)(v.egi(TE_E_EPISODE) + 1);
   v.esi(TE_E_EPISODE, (int)episode);
   v.esi(TE_E_STEP, 0); v.esi(TE_E_MAX_STEP, c.max_step); v.esi(TE_E_ROUND, 1);
@@ -324,13 +351,12 @@ template <class V> TE_DEV void level4_reset_env(const te_config& c, const V& v, 
   v.esf(TE_E_LAST_DIST, c.dome_radius);
 #pragma unroll
   for (int k = 0; k < 4; ++k) v.esf(TE_E_LAST_ACTION + k, 0.0f);
-  for (int p = 0; p < c.n_pursuers; ++p) disarm(v, p);
-  level4_setup_round(c, v, 1, episode);
-  for (int p = 0; p < c.n_pursuers; ++p) {
-    U4 r = env_rng(c, v.env, RNG_SPAWN_PURSUER, (uint32_t)p, 0, episode, 0);
-    respawn_armed(c, v, p, level4_position(c, c.pursuer_spawn_radius, u01(r.x), u01(r.y)));
-  }
-  level4_refresh_snapshot(v);
+  v.esi(TE_E_SNAP_MASK, (int)level4_mask_after_spawn(c, v, 1, true));
+  return episode;
+}
+template <class V> TE_DEV void level4_reset_env(const te_config& c, const V& v, bool prepare = true) {
+  const uint32_t episode = level4_reset_record(c, v);
+  for (int s = 0; s < v.D; ++s) level4_spawn_slot(c, v, s, 1, episode, true);
   if (prepare) prepare_level4_commands(c, v);
 }
 
@@ -589,6 +615,7 @@ TE_DEV void emit_and_finish(const te_config& c, const SView& v, int step, bool t
   const bool to_terminal = term && c.auto_reset;
   v.sm[v.at(v.r.done())] = to_terminal ? 1u : 0u;
   v.sm[v.at(v.r.hitmask())] = resolve_hits(v);  // compute_observation happens before on_step_end
+  TE_LSTAMP(12);
   if (to_terminal) {  // SB3 VecEnv auto-reset: the terminal observation goes aside (rare: straight from this lane)
     float in[TE_OBS_INERTIAL_WORDS], la[4];
     inertial_obs(c, v, step, in);
@@ -597,7 +624,15 @@ TE_DEV void emit_and_finish(const te_config& c, const SView& v, int step, bool t
     write_obs_rows(o.term, v.env, in, la);
   }
   finish();
-  if (to_terminal) reset_env<FAMILY>(c, v, false);
+  TE_LSTAMP(13);
+  if (to_terminal) {
+    if (FAMILY == FAM_LEVEL4) {  // env record now; the D slots are respawned by the whole block (spawn phase)
+      level4_reset_record(c, v);
+      v.sm[v.at(v.r.task())] = 1u | (1u << 8);
+      v.pre_valid = false;
+    } else reset_env<FAMILY>(c, v, false);
+  }
+  TE_LSTAMP(14);
   // the main inertial / last_action rows (post-reset values for an auto-reset env) and the scripted
   // commands of the next step are produced by the whole block afterwards (emit_rows / prepare phase)
   v.sm[v.at(v.r.prevalid())] = v.pre_valid ? 1u : 0u;
@@ -664,6 +699,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
       if (p == 0) agent_shots += 1; else ally_shots += 1;
     }
   }
+  TE_LSTAMP(8);
   // process_explosion_range_invaders (:359-390) on the same (stale) distances
   for (int p = 0; p < Pn; ++p) {
     if (!((S >> p) & 1u)) continue;
@@ -685,6 +721,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
   for (int j = Pn; j < D; ++j)
     if (((S >> j) & 1u) && in_origin(c, v, j)) disarm(v, j);
 
+  TE_LSTAMP(9);
   // compute_reward (:423-515)
   float reward;
   const V3 apos = obs_pos(v, 0);
@@ -717,6 +754,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
     if (dist_origin > c.born_radius - 2.0f) penalty += dist_origin - c.born_radius - 2.0f;  // literal
     reward = score + bonus - penalty;
   }
+  TE_LSTAMP(10);
   // increment_max_step (:150-153)
   int max_step = v.egi(TE_E_MAX_STEP);
   if (agent_shots + ally_shots > 0) { max_step += c.step_increment; v.esi(TE_E_MAX_STEP, max_step); }
@@ -732,6 +770,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
       if (((S >> s) & 1u) && outside_dome(c, v, s)) term = true;
     if (armed_pursuers == 0 || !v.gi(TE_D_ARMED, 0) || apos.z < -5.99f) term = true;
   }
+  TE_LSTAMP(11);
   // info (:571-578)
   o.reward[v.env] = reward;
   o.done[v.env] = term ? 1 : 0;
@@ -741,8 +780,9 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
     if (!term && armed_invaders == 0 && armed_pursuers > 0) {
       int next = round + (round < c.n_rounds ? 1 : c.n_rounds);  // advance_round (:155-175)
       v.esi(TE_E_ROUND, next);
-      level4_setup_round(c, v, next, episode);
-      level4_refresh_snapshot(v);
+      v.esi(TE_E_SNAP_MASK, (int)level4_mask_after_spawn(c, v, next, false));
+      v.sm[v.at(v.r.task())] = (uint32_t)next;  // the D slots are respawned by the whole block (spawn phase)
+      v.pre_valid = false;
     }
   });
 }
