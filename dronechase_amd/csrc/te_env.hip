@@ -234,9 +234,13 @@ __global__ __launch_bounds__(256) void prepare_commands_kernel(Params p) {
 // memory latencies here instead of one per row.
 TE_DEV const uint32_t* staged_row_ptr(const Params& p, const Rows& r, int row, uint32_t inv_d, size_t col) {
   const int D = p.D;
-  if (row < r.agent()) {  // OBS_POS (3*D rows) then ARMED..NAV_STATE (4*D rows): plane = base word + row / D
+  if (row < r.munition()) {  // OBS_POS (3*D rows) then ARMED (D rows): plane = base word + row / D
     int q = (int)(((uint32_t)row * inv_d) >> 16), s = row - q * D;   // exact for row < 65536 / D
-    int w = q < 3 ? TE_D_OBS_POS + q : TE_D_ARMED + (q - 3);
+    int w = q < 3 ? TE_D_OBS_POS + q : TE_D_ARMED;
+    return p.dstate + ((size_t)w * D + s) * p.Npad + col;
+  }
+  if (row < r.agent()) {     // MUNITION, LAST_FIRED of the P pursuers
+    const int k = row - r.munition(), w = k < r.P ? TE_D_MUNITION : TE_D_LAST_FIRED, s = k < r.P ? k : k - r.P;
     return p.dstate + ((size_t)w * D + s) * p.Npad + col;
   }
   if (row < r.env()) return p.dstate + ((size_t)(TE_D_OBS_EULER + (row - r.agent())) * D) * p.Npad + col;

@@ -38,8 +38,10 @@ struct Rows {
   int D, P;
   TE_DEV int I() const { return D - P; }
   TE_DEV int obs_pos() const { return 0; }                  // 3*D : word-major, slot-minor
-  TE_DEV int flags() const { return 3 * D; }                // 4*D : ARMED, MUNITION, LAST_FIRED, NAV_STATE
-  TE_DEV int agent() const { return 7 * D; }                // 9   : OBS_EULER, OBS_VEL, OBS_RATE of slot 0
+  TE_DEV int armed() const { return 3 * D; }                // D   : ARMED
+  TE_DEV int munition() const { return 4 * D; }             // P   : MUNITION of the pursuers (nobody reads an invader's gun)
+  TE_DEV int last_fired() const { return 4 * D + P; }       // P   : LAST_FIRED of the pursuers
+  TE_DEV int agent() const { return 4 * D + 2 * P; }        // 9   : OBS_EULER, OBS_VEL, OBS_RATE of slot 0
   TE_DEV int env() const { return agent() + 9; }            // TE_ENV_WORDS
   TE_DEV int staged() const { return env() + TE_ENV_WORDS; }  // rows loaded from global memory
   TE_DEV int rinv() const { return staged(); }              // 9   : inverse attitude of the agent (row-major)
@@ -54,7 +56,7 @@ struct Rows {
   TE_DEV int task() const { return prevalid() + 1; }        // 1   : level4 spawn work left to the block: round | reset << 8
   TE_DEV int total() const { return task() + 1; }
 };
-__host__ __device__ inline int lds_rows(int D, int P) { return 9 * D + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 6; }
+__host__ __device__ inline int lds_rows(int D, int P) { return 6 * D + 2 * P + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 6; }
 
 struct SView {
   GView g; uint32_t* sm; int lane; Rows r;
@@ -64,7 +66,9 @@ struct SView {
   // LDS address of a staged drone word, or -1
   TE_DEV int dmap(int w, int s) const {
     if (w >= TE_D_OBS_POS && w < TE_D_OBS_POS + 3) return at(r.obs_pos() + (w - TE_D_OBS_POS) * D + s);
-    if (w >= TE_D_ARMED && w <= TE_D_NAV_STATE) return at(r.flags() + (w - TE_D_ARMED) * D + s);
+    if (w == TE_D_ARMED) return at(r.armed() + s);
+    if (w == TE_D_MUNITION && s < P) return at(r.munition() + s);
+    if (w == TE_D_LAST_FIRED && s < P) return at(r.last_fired() + s);
     if (s == 0 && w >= TE_D_OBS_EULER && w < TE_D_OBS_EULER + 9) return at(r.agent() + (w - TE_D_OBS_EULER));
     return -1;
   }
@@ -506,6 +510,7 @@ TE_DEV void precompute_block(const te_config& c, uint32_t* sm, const Rows& r) {
     for (int k = 0; k < 9; ++k) sm[(r.rinv() + k) * kEPB + l] = __float_as_uint(m[k]);
     uint32_t zone = 0, org = 0;
     for (int s = 0; s < D; ++s) {
+      if (!sm[(r.armed() + s) * kEPB + l]) continue;  // every reader masks these bits with the armed snapshot
       float n = norm(pos(s, l));
       zone |= (n > c.dome_radius ? 1u : 0u) << s;
       org |= (n < c.origin_range ? 1u : 0u) << s;
@@ -516,12 +521,14 @@ TE_DEV void precompute_block(const te_config& c, uint32_t* sm, const Rows& r) {
     for (int it = tid - kEPB; it < kEPB * P * I; it += nt - kEPB) {
       int l = it & (kEPB - 1), pj = it / kEPB;
       int pp = pj / I, j = P + pj - pp * I;
+      if (!sm[(r.armed() + j) * kEPB + l]) continue;  // read only for pairs of the armed snapshot
       sm[(r.dpi() + pj) * kEPB + l] = __float_as_uint(dist(pos(pp, l), pos(j, l)));
     }
   }
   __syncthreads();
   for (int it = tid; it < kEPB * (D - 1); it += nt) {  // LIDAR features (fused_lidar.py:143-217), one per (env, other drone)
     int l = it & (kEPB - 1), j = 1 + it / kEPB;
+    if (!sm[(r.armed() + j) * kEPB + l]) continue;  // resolve_hits() looks at armed drones only (and none is armed later)
     M3 R{__uint_as_float(sm[(r.rinv() + 0) * kEPB + l]), __uint_as_float(sm[(r.rinv() + 1) * kEPB + l]), __uint_as_float(sm[(r.rinv() + 2) * kEPB + l]),
          __uint_as_float(sm[(r.rinv() + 3) * kEPB + l]), __uint_as_float(sm[(r.rinv() + 4) * kEPB + l]), __uint_as_float(sm[(r.rinv() + 5) * kEPB + l]),
          __uint_as_float(sm[(r.rinv() + 6) * kEPB + l]), __uint_as_float(sm[(r.rinv() + 7) * kEPB + l]), __uint_as_float(sm[(r.rinv() + 8) * kEPB + l])};
@@ -653,7 +660,7 @@ TE_DEV void emit_rows(const te_config& c, const uint32_t* sm, const Rows& r, con
       else if (k < 12) val = clampf(__uint_as_float(sm[(r.agent() + 6 + (k - 9)) * kEPB + l]) / (2.0f * kPi), -1.0f, 1.0f);
       else {
         float g[3];
-        gun_state(c, (int)sm[(r.flags() + 1 * D) * kEPB + l], (int)sm[(r.flags() + 2 * D) * kEPB + l],
+        gun_state(c, (int)sm[r.munition() * kEPB + l], (int)sm[r.last_fired() * kEPB + l],
                   (int)sm[(r.env() + TE_E_STEP) * kEPB + l], max_munition_of(c, 0), g);
         val = g[k - 12];
       }
