@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void observe_kernel(Params p, ObsOut o) {
     const int lane = threadIdx.x;
     SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + lane, r.P}, sm, lane, r, p.D, r.P, env0 + lane, true};
     // right after a reset the Delta=1 snapshot does not exist yet: empty sphere
-    if (v.egi(TE_E_STEP) != 0) sm[r.hitmask() * kEPB + lane] = resolve_hits(v);
+    if (v.egi(TE_E_STEP) != 0) sm[r.hitmask() * kEPB + lane] = resolve_hits(v, armed_mask(v));
   }
   __syncthreads();
   emit_rows(p.cfg, sm, r, o, env0, nvalid, threadIdx.x, blockDim.x);

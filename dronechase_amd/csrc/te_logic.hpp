@@ -54,9 +54,10 @@ struct Rows {
   TE_DEV int done() const { return hitmask() + 1; }         // 1   : env auto-reset this step
   TE_DEV int prevalid() const { return done() + 1; }        // 1   : distance / zone rows still valid after the logic
   TE_DEV int task() const { return prevalid() + 1; }        // 1   : level4 spawn work left to the block: round | reset << 8
-  TE_DEV int total() const { return task() + 1; }
+  TE_DEV int smask() const { return task() + 1; }           // 1   : bit s = drone s armed when the block was staged
+  TE_DEV int total() const { return smask() + 1; }
 };
-__host__ __device__ inline int lds_rows(int D, int P) { return 6 * D + 2 * P + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 6; }
+__host__ __device__ inline int lds_rows(int D, int P) { return 6 * D + 2 * P + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 7; }
 
 struct SView {
   GView g; uint32_t* sm; int lane; Rows r;
@@ -508,14 +509,15 @@ TE_DEV void precompute_block(const te_config& c, uint32_t* sm, const Rows& r) {
     const float m[9] = {R.m00, R.m01, R.m02, R.m10, R.m11, R.m12, R.m20, R.m21, R.m22};
 #pragma unroll
     for (int k = 0; k < 9; ++k) sm[(r.rinv() + k) * kEPB + l] = __float_as_uint(m[k]);
-    uint32_t zone = 0, org = 0;
+    uint32_t zone = 0, org = 0, armed = 0;
     for (int s = 0; s < D; ++s) {
       if (!sm[(r.armed() + s) * kEPB + l]) continue;  // every reader masks these bits with the armed snapshot
+      armed |= 1u << s;
       float n = norm(pos(s, l));
       zone |= (n > c.dome_radius ? 1u : 0u) << s;
       org |= (n < c.origin_range ? 1u : 0u) << s;
     }
-    sm[r.zone() * kEPB + l] = zone; sm[r.origin() * kEPB + l] = org;
+    sm[r.zone() * kEPB + l] = zone; sm[r.origin() * kEPB + l] = org; sm[r.smask() * kEPB + l] = armed;
     sm[r.hitmask() * kEPB + l] = 0u; sm[r.done() * kEPB + l] = 0u;
   } else {           // waves 1..: pursuer-invader distance matrix
     for (int it = tid - kEPB; it < kEPB * P * I; it += nt - kEPB) {
@@ -541,10 +543,10 @@ TE_DEV void precompute_block(const te_config& c, uint32_t* sm, const Rows& r) {
 
 // LidarMath.add_features (lidar_math.py:262-311), closer wins with a strict '<' in slot order, over the
 // drones armed NOW: bit j of the result = drone j owns its cell.
-TE_DEV uint32_t resolve_hits(const SView& v) {
+TE_DEV uint32_t resolve_hits(const SView& v, uint32_t armed_now) {
   uint32_t owners = 0;
-  for (int j = 1; j < v.D; ++j) {
-    if (!v.gi(TE_D_ARMED, j)) continue;
+  for (uint32_t todo = armed_now & ~1u; todo; todo &= todo - 1) {
+    const int j = __ffs(todo) - 1;
     const int cell = (int)v.sm[v.at(v.r.lcell() + j)];
     const float rhat = __uint_as_float(v.sm[v.at(v.r.lrhat() + j)]);
     bool placed = false;
@@ -618,10 +620,10 @@ TE_DEV void stream_terminal_ones(const uint32_t* sm, const Rows& r, float* __res
 // Common tail of every family's step: observation of THIS step (to the terminal buffers when the env
 // auto-resets), then `finish` (on_step_end / respawn), then the reset + reset observation.
 template <int FAMILY, class FinishFn>
-TE_DEV void emit_and_finish(const te_config& c, const SView& v, int step, bool term, const StepOut& o, FinishFn finish) {
+TE_DEV void emit_and_finish(const te_config& c, const SView& v, int step, bool term, uint32_t armed_now, const StepOut& o, FinishFn finish) {
   const bool to_terminal = term && c.auto_reset;
   v.sm[v.at(v.r.done())] = to_terminal ? 1u : 0u;
-  v.sm[v.at(v.r.hitmask())] = resolve_hits(v);  // compute_observation happens before on_step_end
+  v.sm[v.at(v.r.hitmask())] = resolve_hits(v, armed_now);  // compute_observation happens before on_step_end
   TE_LSTAMP(12);
   if (to_terminal) {  // SB3 VecEnv auto-reset: the terminal observation goes aside (rare: straight from this lane)
     float in[TE_OBS_INERTIAL_WORDS], la[4];
@@ -676,13 +678,20 @@ TE_DEV void emit_rows(const te_config& c, const uint32_t* sm, const Rows& r, con
 // Task.on_step_middle + compute_info + compute_observation + on_step_end, then SB3 auto-reset.
 // ------------------------------------------------------------------------------------------------
 TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, const StepOut& o) {
-  const int Pn = c.n_pursuers, D = v.D;
+  const int Pn = c.n_pursuers;
   v.esf(TE_E_LAST_ACTION + 0, action.x); v.esf(TE_E_LAST_ACTION + 1, action.y);
   v.esf(TE_E_LAST_ACTION + 2, action.z); v.esf(TE_E_LAST_ACTION + 3, action.w);
   const int step = v.egi(TE_E_STEP) + 1;  // AGENT_STEP_BROADCAST (exp03_vFinal_environment.py:177-182)
   v.esi(TE_E_STEP, step);
   const uint32_t episode = (uint32_t)v.egi(TE_E_EPISODE);
-  const uint32_t S = armed_mask(v);  // OffsetHandler.on_middle_step: drones armed now
+  // OffsetHandler.on_middle_step snapshot: drones armed now.  S and the dome / origin flags are bit masks from the
+  // precompute phase, and A tracks who is STILL armed as the engagement disarms drones, so the per-slot questions
+  // below are bit operations instead of LDS round trips in loops the compiler cannot unroll (D is a run-time value).
+  const uint32_t S = v.sm[v.at(v.r.smask())];
+  const uint32_t zone = v.sm[v.at(v.r.zone())] & S, org = v.sm[v.at(v.r.origin())] & S;
+  const uint32_t pur_bits = (1u << Pn) - 1u, inv_bits = ~pur_bits;
+  uint32_t A = S;
+  auto kill = [&](int j) { disarm(v, j); A &= ~(1u << j); };
   v.esi(TE_E_SNAP_MASK, (int)S);
 
   // closest invader of every pursuer over the snapshot, once: identify_invaders_in_range(R)[p][0] is that
@@ -702,7 +711,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
     v.si(TE_D_LAST_FIRED, p, step);
     U4 r = env_rng(c, v.env, RNG_HIT, (uint32_t)p, 0, episode, (uint32_t)step);
     if (u01(r.x) < c.hit_prob) {  // gun.py:94; entities_manager.shoot_by_ids (:238-248)
-      disarm(v, tgt);
+      kill(tgt);
       if (p == 0) agent_shots += 1; else ally_shots += 1;
     }
   }
@@ -713,8 +722,8 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
     int tgt; float dmin;
     if (p < 2) { tgt = tgt_of[p]; dmin = dmin_of[p]; } else tgt = closest_invader(v, S, p, dmin);
     if (tgt < 0 || !(dmin < c.explosion_range)) continue;
-    disarm(v, p);
-    disarm(v, tgt);
+    kill(p);
+    kill(tgt);
     int mun = v.gi(TE_D_MUNITION, p);
     if (mun == 0 && p == 0) agent_suicided += 1;
     else if (mun == 0) pursuer_suicided += 1;
@@ -725,8 +734,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
   const int deads = v.egi(TE_E_DEADS) + exploded;
   v.esi(TE_E_AGENT_KILLS, agent_kills); v.esi(TE_E_ALLIES_KILLS, allies_kills); v.esi(TE_E_DEADS, deads);
   // process_invaders_in_origin (:656-659)
-  for (int j = Pn; j < D; ++j)
-    if (((S >> j) & 1u) && in_origin(c, v, j)) disarm(v, j);
+  for (uint32_t m = org & inv_bits; m; m &= m - 1) kill(__ffs(m) - 1);
 
   TE_LSTAMP(9);
   // compute_reward (:423-515)
@@ -754,10 +762,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
     if (ally_shots > 0 || pursuer_suicided > 0) bonus += 0.5f * (float)(ally_shots + pursuer_suicided) * 1000.0f;
     else if (exploded > 0) penalty += 1000.0f * (float)exploded;
     if (apos.z < -5.0f) penalty += (-5.0f - apos.z) * 1000.0f;
-    bool outside = false;
-    for (int p = 0; p < Pn; ++p)
-      if (((S >> p) & 1u) && outside_dome(c, v, p)) outside = true;
-    if (outside) penalty += 1000.0f;
+    if (zone & pur_bits) penalty += 1000.0f;  // any armed pursuer outside the dome
     if (dist_origin > c.born_radius - 2.0f) penalty += dist_origin - c.born_radius - 2.0f;  // literal
     reward = score + bonus - penalty;
   }
@@ -766,23 +771,19 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
   int max_step = v.egi(TE_E_MAX_STEP);
   if (agent_shots + ally_shots > 0) { max_step += c.step_increment; v.esi(TE_E_MAX_STEP, max_step); }
   // compute_termination (:517-569)
-  int armed_invaders = 0, armed_pursuers = 0;
-  for (int j = Pn; j < D; ++j) armed_invaders += v.gi(TE_D_ARMED, j) ? 1 : 0;
-  for (int p = 0; p < Pn; ++p) armed_pursuers += v.gi(TE_D_ARMED, p) ? 1 : 0;
+  const int armed_invaders = __popc(A & inv_bits), armed_pursuers = __popc(A & pur_bits);
   const int round = v.egi(TE_E_ROUND);
   const bool all_rounds_over = armed_invaders == 0 && round >= c.n_rounds;
   bool term = step > max_step || all_rounds_over;
   if (!term) {
-    for (int s = 0; s < D; ++s)
-      if (((S >> s) & 1u) && outside_dome(c, v, s)) term = true;
-    if (armed_pursuers == 0 || !v.gi(TE_D_ARMED, 0) || apos.z < -5.99f) term = true;
+    if (zone || armed_pursuers == 0 || !(A & 1u) || apos.z < -5.99f) term = true;
   }
   TE_LSTAMP(11);
   // info (:571-578)
   o.reward[v.env] = reward;
   o.done[v.env] = term ? 1 : 0;
   reinterpret_cast<int4*>(o.info)[v.env] = make_int4(agent_kills, allies_kills, deads, round);
-  emit_and_finish<FAM_LEVEL4>(c, v, step, term, o, [&]() {
+  emit_and_finish<FAM_LEVEL4>(c, v, step, term, A, o, [&]() {
     // on_step_end (:321-333): next wave when this one is cleared and a pursuer is alive
     if (!term && armed_invaders == 0 && armed_pursuers > 0) {
       int next = round + (round < c.n_rounds ? 1 : c.n_rounds);  // advance_round (:155-175)
@@ -853,7 +854,7 @@ TE_DEV void stage02_logic(const te_config& c, const SView& v, float4 action, con
   reinterpret_cast<int4*>(o.info)[v.env] = make_int4(kills, 0, deads, 0);
   // the observation is taken before the respawn: a drone armed after the step broadcast has no
   // Delta=1 snapshot yet (lidar_buffer.py:443-447) and is invisible this step
-  emit_and_finish<FAM_STAGE02>(c, v, step, term, o, [&]() {
+  emit_and_finish<FAM_STAGE02>(c, v, step, term, armed_mask(v), o, [&]() {
     for (int j = Pn; j < D; ++j)  // respawn killed invaders (stages.py:167-174)
       if (!v.gi(TE_D_ARMED, j)) respawn_armed(c, v, j, stage02_invader_position(c, v.env, j, episode, (uint32_t)step));
     v.esf(TE_E_PREV_SNAP_MIN, cur); v.esf(TE_E_LAST_DIST, cur);  // on_step_end: last_offsets = current_offsets
@@ -880,7 +881,7 @@ TE_DEV void stage01_logic(const te_config& c, const SView& v, float4 action, con
   o.reward[v.env] = reward;
   o.done[v.env] = term ? 1 : 0;
   reinterpret_cast<int4*>(o.info)[v.env] = make_int4(kills, 0, 0, 0);
-  emit_and_finish<FAM_STAGE01>(c, v, step, term, o, [&]() {
+  emit_and_finish<FAM_STAGE01>(c, v, step, term, armed_mask(v), o, [&]() {
     if (d < c.catch_distance) {  // replace_invader_if_close (:147-154)
       stage01_replace_invader(c, v, stage01_cube(c, v.env, RNG_RESPAWN, 2, episode, (uint32_t)step), episode, (uint32_t)step);
       v.esi(TE_E_AGENT_KILLS, kills);
