@@ -26,6 +26,9 @@ enum { TE_X_CMD = TE_DRONE_WORDS, /* 3: velocity command vx,vy,vz of a scripted 
 struct Derived {
   float invT, dt, k_motor, noise_ratio, q_thrust, q_arm, q_torque, k_drag, k_pqr;
   float dt_inv_ix, dt_inv_iy, dt_inv_iz, ix, iy, iz, dt_inv_m, dt_g, pwm_floor;
+  // PID gains with the controller period folded in: ki * T and kd / T
+  float lv_kiT[2], lv_kdT[2], av_kiT[3], av_kdT[3], zv_kiT, zv_kdT;
+  float half_dt, quarter_dt2, noise_m2ln2;  // dt/2, dt^2/4, -2 ln 2 * noise_ratio^2 (Box-Muller radius incl. the noise gain)
 };
 struct Params {
   te_config cfg;
@@ -124,7 +127,8 @@ TE_DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 TE_DEV float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // ---------------------------------------------------------------- small math
-TE_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// lo <= hi everywhere it is used: the median of (x, lo, hi) IS the clamp, in one v_med3_f32 instead of v_max + v_min
+TE_DEV float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 // gfx950 native transcendentals (1 ulp class, quarter-rate VALU) instead of the branchy libm slow paths:
 // the sub-step loop is VALU-issue-bound, so instruction count is the lever.
@@ -134,6 +138,7 @@ TE_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }         // v_s
 TE_DEV float sin_rev(float r) { return __builtin_amdgcn_sinf(r); }        // v_sin_f32: sin(2 pi r)
 TE_DEV float cos_rev(float r) { return __builtin_amdgcn_cosf(r); }        // v_cos_f32: cos(2 pi r)
 TE_DEV float ln(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }  // v_log_f32 is log2
+TE_DEV float log2_native(float x) { return __builtin_amdgcn_logf(x); }
 // atan on [0, inf) by one reduction around tan(pi/8) + a degree-4 odd minimax (Cephes atanf), ~1e-7 abs
 TE_DEV float atan_poly(float x) {
   float z = x * x;
@@ -176,6 +181,15 @@ TE_DEV M3 rotation(Q4 q) {
   float d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
   float s = 2.0f * rcp(d);
   float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+  float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+  float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+  return M3{1.0f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0f - (xx + yy)};
+}
+// the same for a quaternion that is already normalised (the sub-step loop renormalises b.q every sub-step, as
+// Bullet's integrator does): s = 2 / |q|^2 = 2 up to 1e-7, no reciprocal
+TE_DEV M3 rotation_unit(Q4 q) {
+  float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
   float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
   float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
   float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
@@ -230,15 +244,20 @@ __host__ __device__ inline Derived derive(const te_config& c) {
   d.ix = q.inertia[0]; d.iy = q.inertia[1]; d.iz = q.inertia[2];
   d.dt_inv_ix = c.physics_dt / q.inertia[0]; d.dt_inv_iy = c.physics_dt / q.inertia[1]; d.dt_inv_iz = c.physics_dt / q.inertia[2];
   d.dt_inv_m = c.physics_dt / q.mass; d.dt_g = c.physics_dt * q.gravity; d.pwm_floor = q.pwm_floor;
+  for (int i = 0; i < 2; ++i) { d.lv_kiT[i] = q.lin_vel_ki[i] * c.control_dt; d.lv_kdT[i] = q.lin_vel_kd[i] / c.control_dt; }
+  for (int i = 0; i < 3; ++i) { d.av_kiT[i] = q.ang_vel_ki[i] * c.control_dt; d.av_kdT[i] = q.ang_vel_kd[i] / c.control_dt; }
+  d.zv_kiT = q.z_vel_ki * c.control_dt; d.zv_kdT = q.z_vel_kd / c.control_dt;
+  d.half_dt = 0.5f * c.physics_dt; d.quarter_dt2 = 0.25f * c.physics_dt * c.physics_dt;
+  d.noise_m2ln2 = -2.0f * 0.69314718056f * q.noise_ratio * q.noise_ratio;
   return d;
 }
 
-// PyFlyt PID.step
-TE_DEV float pid(float kp, float ki, float kd, float lim, float T, float invT, float err, float& I, float& prev) {
-  I = clampf(I + ki * err * T, -lim, lim);
-  float Dv = kd * (err - prev) * invT;
+// PyFlyt PID.step with the period folded into the gains (kiT = ki * T, kdT = kd / T): 2 fma + 2 clamps + 1 sub
+TE_DEV float pid(float kp, float kiT, float kdT, float lim, float err, float& I, float& prev) {
+  I = clampf(fmaf(kiT, err, I), -lim, lim);
+  const float d = err - prev;
   prev = err;
-  return clampf(kp * err + I + Dv, -lim, lim);
+  return clampf(fmaf(kp, err, fmaf(kdT, d, I)), -lim, lim);
 }
 
 // Motor noise: 4 standard normals per sub-step.  One Philox4x32-10 call (40 quarter-rate integer multiplies)
@@ -258,9 +277,10 @@ TE_DEV U4 motor_noise_bits(const te_config& c, int env, int slot, uint32_t episo
   return philox4x32_10((uint32_t)g, RNG_MOTOR | ((uint32_t)slot << 8) | ((uint32_t)(sub >> 1) << 16) | ((uint32_t)(g >> 32) << 24),
                        episode, step_index, k0, k1);
 }
-TE_DEV void motor_noise_from(uint32_t a, uint32_t b, float nz[4]) {
+// `m2ln2_gain2` = -2 ln 2 * gain^2: the normals come out already multiplied by the noise gain.
+TE_DEV void motor_noise_from(uint32_t a, uint32_t b, float m2ln2_gain2, float nz[4]) {
   const float k16 = 1.0f / 65536.0f;
-  float r0 = fsqrt(-2.0f * ln(((float)(a & 0xFFFFu) + 0.5f) * k16)), r1 = fsqrt(-2.0f * ln(((float)(b & 0xFFFFu) + 0.5f) * k16));
+  float r0 = fsqrt(m2ln2_gain2 * log2_native(((float)(a & 0xFFFFu) + 0.5f) * k16)), r1 = fsqrt(m2ln2_gain2 * log2_native(((float)(b & 0xFFFFu) + 0.5f) * k16));
   float a0 = (float)(a >> 16) * k16, a1 = (float)(b >> 16) * k16;  // revolutions
   nz[0] = r0 * cos_rev(a0); nz[1] = r0 * sin_rev(a0); nz[2] = r1 * cos_rev(a1); nz[3] = r1 * sin_rev(a1);
 }
@@ -279,8 +299,8 @@ template <bool MODE7, bool CAPTURE, bool NOISE>
 TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float sp[4], uint32_t noise_a, uint32_t noise_b,
                     V3& pend_f, V3& pend_t) {
   const te_quad_params& qp = c.quad;
-  const float T = c.control_dt, dt = k.dt;
-  M3 R = rotation(b.q);
+  const float dt = k.dt;
+  M3 R = rotation_unit(b.q);
   // ---- IMU (imu.py:27-41)
   V3 vb = mulT(R, b.vel);
   float sarg = -R.m20;
@@ -310,18 +330,18 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
     zc = clampf(qp.z_pos_kp * (zc - b.pos.z), -qp.z_pos_lim, qp.z_pos_lim);
   }
   float u = cyaw * a0 + syaw * a1, v = -syaw * a0 + cyaw * a1;
-  float ox = pid(qp.lin_vel_kp[0], qp.lin_vel_ki[0], qp.lin_vel_kd[0], qp.lin_vel_lim[0], T, k.invT, u - vb.x, b.lv_i[0], b.lv_e[0]);
-  float oy = pid(qp.lin_vel_kp[1], qp.lin_vel_ki[1], qp.lin_vel_kd[1], qp.lin_vel_lim[1], T, k.invT, v - vb.y, b.lv_i[1], b.lv_e[1]);
+  float ox = pid(qp.lin_vel_kp[0], k.lv_kiT[0], k.lv_kdT[0], qp.lin_vel_lim[0], u - vb.x, b.lv_i[0], b.lv_e[0]);
+  float oy = pid(qp.lin_vel_kp[1], k.lv_kiT[1], k.lv_kdT[1], qp.lin_vel_lim[1], v - vb.y, b.lv_i[1], b.lv_e[1]);
   float r0 = clampf(qp.ang_pos_kp[0] * (-oy - roll), -qp.ang_pos_lim[0], qp.ang_pos_lim[0]);
   float r1 = clampf(qp.ang_pos_kp[1] * (ox - pitch), -qp.ang_pos_lim[1], qp.ang_pos_lim[1]);
-  float t0 = pid(qp.ang_vel_kp[0], qp.ang_vel_ki[0], qp.ang_vel_kd[0], qp.ang_vel_lim[0], T, k.invT, r0 - b.wb.x, b.av_i[0], b.av_e[0]);
-  float t1 = pid(qp.ang_vel_kp[1], qp.ang_vel_ki[1], qp.ang_vel_kd[1], qp.ang_vel_lim[1], T, k.invT, r1 - b.wb.y, b.av_i[1], b.av_e[1]);
-  float t2 = pid(qp.ang_vel_kp[2], qp.ang_vel_ki[2], qp.ang_vel_kd[2], qp.ang_vel_lim[2], T, k.invT, sp[2] - b.wb.z, b.av_i[2], b.av_e[2]);
-  float th = pid(qp.z_vel_kp, qp.z_vel_ki, qp.z_vel_kd, qp.z_vel_lim, T, k.invT, zc - vb.z, b.zv_i, b.zv_e);
+  float t0 = pid(qp.ang_vel_kp[0], k.av_kiT[0], k.av_kdT[0], qp.ang_vel_lim[0], r0 - b.wb.x, b.av_i[0], b.av_e[0]);
+  float t1 = pid(qp.ang_vel_kp[1], k.av_kiT[1], k.av_kdT[1], qp.ang_vel_lim[1], r1 - b.wb.y, b.av_i[1], b.av_e[1]);
+  float t2 = pid(qp.ang_vel_kp[2], k.av_kiT[2], k.av_kdT[2], qp.ang_vel_lim[2], sp[2] - b.wb.z, b.av_i[2], b.av_e[2]);
+  float th = pid(qp.z_vel_kp, k.zv_kiT, k.zv_kdT, qp.z_vel_lim, zc - vb.z, b.zv_i, b.zv_e);
   th = clampf(th, 0.0f, 1.0f);
   float pwm[4] = {-t0 - t1 + t2 + th, t0 + t1 + t2 + th, -t0 + t1 - t2 + th, t0 - t1 - t2 + th};
   float hi = fmaxf(fmaxf(pwm[0], pwm[1]), fmaxf(pwm[2], pwm[3]));
-  if (hi > 1.0f) {
+  if (__builtin_amdgcn_ballot_w64(hi > 1.0f) != 0ull && hi > 1.0f) {  // wave-uniform test first: saturation is rare
     float s = rcp(hi);
 #pragma unroll
     for (int i = 0; i < 4; ++i) pwm[i] *= s;
@@ -334,12 +354,12 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
   }
   // ---- motors (first-order lag, multiplicative noise, thrust/torque ~ rpm^2) + drag
   float T_[4], nz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (NOISE) motor_noise_from(noise_a, noise_b, nz);
+  if (NOISE) motor_noise_from(noise_a, noise_b, k.noise_m2ln2, nz);  // nz = noise_ratio * N(0, 1)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float t = b.thr[i];
     t += k.k_motor * (pwm[i] - t);
-    if (NOISE) t += nz[i] * t * k.noise_ratio;
+    if (NOISE) t = fmaf(nz[i], t, t);
     b.thr[i] = t;
     T_[i] = t * t;
   }
@@ -364,14 +384,14 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
   b.vel = V3{b.vel.x + k.dt_inv_m * Fw.x, b.vel.y + k.dt_inv_m * Fw.y, b.vel.z + (k.dt_inv_m * Fw.z - k.dt_g)};
   b.pos = V3{b.pos.x + dt * b.vel.x, b.pos.y + dt * b.vel.y, b.pos.z + dt * b.vel.z};
   float w2 = b.wb.x * b.wb.x + b.wb.y * b.wb.y + b.wb.z * b.wb.z;
-  float h2 = 0.25f * dt * dt * w2;  // (half angle)^2
+  float h2 = k.quarter_dt2 * w2;  // (half angle)^2
   float sc, ch;                     // sin(h)/|w| and cos(h)
   if (h2 < 0.25f) {
-    sc = 0.5f * dt * (1.0f + h2 * (-1.0f / 6.0f + h2 * (1.0f / 120.0f + h2 * (-1.0f / 5040.0f + h2 * (1.0f / 362880.0f)))));
+    sc = k.half_dt * (1.0f + h2 * (-1.0f / 6.0f + h2 * (1.0f / 120.0f + h2 * (-1.0f / 5040.0f + h2 * (1.0f / 362880.0f)))));
     ch = 1.0f + h2 * (-0.5f + h2 * (1.0f / 24.0f + h2 * (-1.0f / 720.0f + h2 * (1.0f / 40320.0f + h2 * (-1.0f / 3628800.0f)))));
   } else {  // > 240 rad/s: native sin/cos (inputs in revolutions) are plenty
     float inv_w = rsq(w2);
-    float rev = 0.5f * dt * (w2 * inv_w) * (0.5f / kPi);
+    float rev = k.half_dt * (w2 * inv_w) * (0.5f / kPi);
     sc = sin_rev(rev) * inv_w; ch = cos_rev(rev);
   }
   Q4 dq{b.wb.x * sc, b.wb.y * sc, b.wb.z * sc, ch};

@@ -37,7 +37,7 @@ namespace te {
 //   [drone waves] wave = slot * (Npad/64) + chunk, SLOT-major: the always-armed slots (agent, allies, the first
 //                 invaders of the current round) reach the SIMDs first, the mostly disarmed slots retire after
 //                 one load.  Chunk-major order let ~6 000 disarmed waves take the issue slots first.
-// Measured on stage03, 65 536 envs (tools/k1_phase.py): chunk-major + per-wave fill 82-93 us; this order 5x-7x us.
+// Measured on stage03, 65 536 envs (tools/k1_phase.py): chunk-major + per-wave fill 82-93 us; this order 53-71 us.
 #ifndef TE_K1_BLOCK
 #define TE_K1_BLOCK 64
 #endif
@@ -46,9 +46,9 @@ namespace te {
 #else
 #define TE_K1_ATTR
 #endif
-// Background job of one launch.  Quads [0, first_quads) are written by the drone waves (one float4 per lane, see
-// the note on register allocation below); [first_quads, total_quads) by the fill waves, quads_per_fill_wave each.
-struct FillJob { float* lidar; uint32_t total_quads; uint32_t n_fill_waves; uint32_t quads_per_fill_wave; uint32_t fill_pos; };
+// Background job of one launch.  The first D * Npad quads are written by the drone waves (one float4 per lane, see
+// the note on register allocation below), the rest by the fill waves, grid-stride.
+struct FillJob { float* lidar; uint32_t total_quads; uint32_t n_fill_waves; };
 
 // what kamikaze_update() reads of the other drones, through the wave's buffer resource
 struct NavView {
@@ -65,15 +65,14 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   const float4 ones = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
   float4* fill_dst = reinterpret_cast<float4*>(fill.lidar);
   if (FILL) {
-    const int fw = wave - (int)fill.fill_pos;  // fill waves sit at launch positions [fill_pos, fill_pos + n_fill_waves)
-    if (fw >= 0 && fw < (int)fill.n_fill_waves) {
-      const uint32_t first = (uint32_t)(D * nchunks) * 64u;
-      uint32_t q = first + (uint32_t)fw * fill.quads_per_fill_wave + (uint32_t)lane;
-      const uint32_t end = min(first + ((uint32_t)fw + 1u) * fill.quads_per_fill_wave, fill.total_quads);
-      for (; q < end; q += 64u) fill_dst[q] = ones;
+    if (wave < (int)fill.n_fill_waves) {  // ---- fill wave
+      // grid-stride: at any moment the fill waves write one contiguous n_fill_waves KB window, which the address
+      // interleave spreads over every HBM channel
+      const uint32_t first = (uint32_t)(D * nchunks) * 64u, stride = fill.n_fill_waves * 64u;
+      for (uint32_t q = first + (uint32_t)wave * 64u + (uint32_t)lane; q < fill.total_quads; q += stride) fill_dst[q] = ones;
       return;
     }
-    if (fw >= 0) wave -= (int)fill.n_fill_waves;
+    wave -= (int)fill.n_fill_waves;
   }
   const int slot = wave / nchunks;
   const int chunk = wave - slot * nchunks;
@@ -146,6 +145,11 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   Body b;
   b.pos = V3{raw[TE_D_POS], raw[TE_D_POS + 1], raw[TE_D_POS + 2]};
   b.q = Q4{raw[TE_D_QUAT], raw[TE_D_QUAT + 1], raw[TE_D_QUAT + 2], raw[TE_D_QUAT + 3]};
+  {  // the loop's rotation_unit() assumes |q| = 1: true for every state this library writes, enforced for blobs
+     // that came in through te_set_state
+    const float inv = rsq(b.q.x * b.q.x + b.q.y * b.q.y + b.q.z * b.q.z + b.q.w * b.q.w);
+    b.q = Q4{b.q.x * inv, b.q.y * inv, b.q.z * inv, b.q.w * inv};
+  }
   b.vel = V3{raw[TE_D_VEL], raw[TE_D_VEL + 1], raw[TE_D_VEL + 2]};
   b.wb = mulT(rotation(b.q), V3{raw[TE_D_OMEGA], raw[TE_D_OMEGA + 1], raw[TE_D_OMEGA + 2]});
 #pragma unroll
@@ -427,7 +431,6 @@ struct te_env {
   int family;
   size_t lds_bytes;
   int n_fill_waves = 256;  // fill waves of the sub-step kernel (one per CU of an MI355X); TE_FILL_WAVES overrides
-  int fill_pos_pct = 0;    // where they sit among the drone waves, in % of the launch (TE_FILL_POS)
   // profiling (te_profile_begin / te_profile_end)
   std::vector<hipEvent_t> events;
   int prof_cap = 0, prof_used = 0;
@@ -489,7 +492,6 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   e->p.kd = derive(*cfg);
   e->p.N = cfg->n_envs; e->p.D = D; e->p.Npad = (cfg->n_envs + 63) / 64 * 64;
   e->lds_bytes = (size_t)lds_rows(D, cfg->n_pursuers) * kEPB * sizeof(uint32_t);
-  if (const char* v = getenv("TE_FILL_POS")) { int n = atoi(v); if (n >= 0 && n <= 100) e->fill_pos_pct = n; }
   if (const char* v = getenv("TE_FILL_WAVES")) { int n = atoi(v); if (n >= 1 && n <= (1 << 20)) e->n_fill_waves = n; }
   {
     hipError_t le = hipSuccess;
@@ -577,14 +579,12 @@ __attribute__((visibility("default"))) int te_step(te_env* e, const float* actio
   const bool noise = p.cfg.motor_noise != 0;
   // LIDAR background: N*1014 floats = quads float4 (+ <4 tail floats).  The drone waves write one float4 per
   // lane; the rest is split evenly over the fill waves.
-  FillJob fill{nullptr, 0u, 0u, 0u, 0u};
+  FillJob fill{nullptr, 0u, 0u};
   const size_t n_floats = (size_t)p.N * TE_OBS_LIDAR_WORDS;
   if (obs_lidar) {
     const size_t quads = n_floats >> 2, first = (size_t)waves * 64;
     if (quads > first && quads < (1ull << 32)) {
-      const uint32_t nf = (uint32_t)e->n_fill_waves;
-      const uint32_t per = (uint32_t)((((quads - first) + nf - 1) / nf + 63) / 64 * 64);
-      fill = FillJob{obs_lidar, (uint32_t)quads, nf, per, (uint32_t)((long long)waves * e->fill_pos_pct / 100)};
+      fill = FillJob{obs_lidar, (uint32_t)quads, (uint32_t)e->n_fill_waves};
       if (n_floats & 3) hipLaunchKernelGGL(fill_ones_kernel, dim3(1), dim3(64), 0, st, obs_lidar + (quads << 2), n_floats & 3);
     } else {  // tiny or huge buffers: plain fill kernel first
       hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, obs_lidar, n_floats);
