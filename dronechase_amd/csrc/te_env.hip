@@ -1,15 +1,17 @@
 // te_env.hip — gfx950 kernels + C ABI of the batched threat-engagement environment.
 //
 // One te_step = two launches on the caller's stream:
-//   K1 substeps_kernel       one wavefront per (drone slot, 64 consecutive envs); armed lanes fly the 16
-//                            physics sub-steps in registers (state read once, written once); waves whose
-//                            slot is disarmed in all 64 envs retire immediately.
-//   K2 engage_observe_kernel one 256-thread block per 64 envs: all four waves stage the words the logic
-//                            reads (IMU positions, flags, env record, actions) in LDS with one round of
-//                            independent coalesced loads; wave 0 then resolves engagement, reward,
-//                            termination, wave progression, auto-reset and the scripted commands of the
-//                            NEXT step (one lane per env) out of LDS; LIDAR hits are binned in LDS and all
-//                            four waves stream the [64,3,13,26] observation tile with 16-byte stores.
+//   K1 substeps_kernel       one wavefront per workgroup.  256 fill waves stream the LIDAR background (ones);
+//                            one drone wave per (slot, 64 consecutive envs), slot-major: armed lanes work out
+//                            their set-point (an invader runs its navigator here) and fly the 16 physics
+//                            sub-steps in registers (state read once, written once); a wave whose slot is
+//                            disarmed in all 64 envs retires after one load.
+//   K2 engage_observe_kernel one 256-thread block per 64 envs, phases separated by barriers: stage the words the
+//                            logic reads in LDS (one round of independent coalesced loads) -> precompute
+//                            distances / masks / LIDAR cells, all threads -> wave 0, one lane per env:
+//                            engagement, reward, termination, info, hit resolution, round / reset decision ->
+//                            spawn phase, one (env, slot) per thread -> observation rows + the allies' commands
+//                            of the next step -> patch the hit cells into the background.
 // No MFMA: this is element-wise physics and byte streaming.
 //
 // Reference citations are file:line under the reference's src/ tree.
