@@ -24,6 +24,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# VALU issue model of the sub-step kernel ("report VALU utilisation next to HBM %"): static count of
+# the loop body, 4 clocks per wave64 VALU instruction, 16 for the quarter-rate ones (tools/loop_cost.py), 1024 SIMDs,
+# 2.4 GHz (rocm-smi reads 2.397 GHz for the whole bench)
+VALU_CLOCKS_PER_DRONE_SUBSTEP = 1950.0
+SIMDS, CLOCK_HZ, SUBSTEPS = 1024, 2.4e9, 16
 
 
 def parse():
@@ -195,6 +200,8 @@ def main():
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": dom_bytes * n_local, "avg_launch_ms": dom_ms,
                                "launches_timed": n_prof, "armed_drones_per_env": armed,
+                               "valu_issue_frac_substeps_kernel": (armed * n_local / 64.0) * SUBSTEPS * VALU_CLOCKS_PER_DRONE_SUBSTEP
+                                                                  / (SIMDS * CLOCK_HZ * k1_ms * 1e-3),
                                "armed_drones_per_env_begin_end": [armed_begin, armed_end]}
             step_ms = k1_ms + k2_ms
             out["roofline_env_step"] = {"bound": "hbm", "achieved": alg * n_local / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Static VALU issue-cycle estimate of the largest loop of a kernel in a hipcc -S listing:
+    python tools/loop_cost.py listing.s [mangled kernel name]
+4 clocks per wave64 VALU instruction, 16 for quarter-rate ones (transcendentals, 32x32 multiplies)."""
 import sys,re
 name=sys.argv[2] if len(sys.argv)>2 else '_ZN2te15substeps_kernelILi0ELb1ELb1EEEvNS_6ParamsEPKfNS_7FillJobE'
 txt=open(sys.argv[1]).read()
