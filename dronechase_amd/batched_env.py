@@ -41,6 +41,13 @@ class BatchedEnv:
         self.reward = torch.empty((N,), **f32)
         self.done = torch.empty((N,), dtype=torch.uint8, device=dev)
         self.info = torch.empty((N, K.INFO_WORDS), dtype=torch.int32, device=dev)
+        self.stacked_mode = bool(cfg.stacked_obs)
+        if self.stacked_mode:  # level5: FusedLIDAR stacked observation instead of the own sphere
+            shape = (N, K.STACK_SPHERES, K.LIDAR_CHANNELS, K.LIDAR_NTHETA, K.LIDAR_NPHI)
+            self.stacked = torch.empty(shape, **f32)
+            self.mask = torch.empty((N, K.STACK_SPHERES), dtype=torch.uint8, device=dev)
+            self.t_stacked = torch.zeros(shape, **f32)
+            self.t_mask = torch.zeros((N, K.STACK_SPHERES), dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self) -> C.c_void_p:
@@ -88,6 +95,20 @@ class BatchedEnv:
                                   self._p(self.last_action), self._p(self.reward), self._p(self.done), self._p(self.info),
                                   self._p(t[0]), self._p(t[1]), self._p(t[2]), self._stream()), "te_step")
         return self.lidar, self.inertial, self.last_action, self.reward, self.done, self.info
+
+    # level5 ---------------------------------------------------------------------------------
+    def observe_stacked(self):
+        _lib.check(self.L.te_observe_stacked(self._h, self._p(self.stacked), self._p(self.mask), self._p(self.inertial),
+                                             self._p(self.last_action), self._stream()), "te_observe_stacked")
+        return self.stacked, self.mask, self.inertial, self.last_action
+
+    def step_stacked(self, actions: torch.Tensor, terminal: bool = True):
+        a = self._check_actions(actions)
+        t = (self.t_stacked, self.t_mask, self.t_inertial, self.t_last_action) if terminal else (None,) * 4
+        _lib.check(self.L.te_step_stacked(self._h, self._p(a), self._p(self.stacked), self._p(self.mask), self._p(self.inertial),
+                                          self._p(self.last_action), self._p(self.reward), self._p(self.done), self._p(self.info),
+                                          self._p(t[0]), self._p(t[1]), self._p(t[2]), self._p(t[3]), self._stream()), "te_step_stacked")
+        return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
 
     def random_actions(self, seed: int, step_index: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:

@@ -7,11 +7,11 @@ from __future__ import annotations
 
 import ctypes as C
 
-TE_ABI_VERSION = 1
+TE_ABI_VERSION = 2
 
-TASK_STAGE01, TASK_STAGE02, TASK_EXP02, TASK_EXP03, TASK_EXP04 = 1, 2, 3, 4, 5
+TASK_STAGE01, TASK_STAGE02, TASK_EXP02, TASK_EXP03, TASK_EXP04, TASK_LEVEL5 = 1, 2, 3, 4, 5, 6
 TASKS = {"stage01": TASK_STAGE01, "stage02": TASK_STAGE02, "exp02": TASK_EXP02, "exp03": TASK_EXP03,
-         "stage03": TASK_EXP03, "exp04": TASK_EXP04}
+         "stage03": TASK_EXP03, "exp04": TASK_EXP04, "level5": TASK_LEVEL5}
 ALLY_NONE, ALLY_BT, ALLY_FROZEN = 0, 1, 2
 
 LIDAR_NTHETA, LIDAR_NPHI, LIDAR_CHANNELS = 13, 26, 3
@@ -22,6 +22,14 @@ OBS_ACTION_WORDS = 4
 INFO_WORDS = 4
 DRONE_WORDS = 58
 ENV_WORDS = 16
+# level5 stacked observation (TE_RING_* / TE_STACK_*)
+RING_DEPTH, STACK_SPHERES = 10, 6
+OBS_STACKED_WORDS = STACK_SPHERES * OBS_LIDAR_WORDS
+RING_HEADER_WORDS, RING_FEATURE_WORDS = 12, 4
+
+
+def ring_entry_words(n_drones: int) -> int:
+    return RING_HEADER_WORDS + RING_FEATURE_WORDS * (n_drones - 1)
 
 # word offsets inside a drone record of the state blob (TE_D_*)
 D = dict(POS=0, QUAT=3, VEL=7, OMEGA=10, THROTTLE=13, PID_AV_I=17, PID_AV_E=20, PID_LV_I=23, PID_LV_E=25,
@@ -64,7 +72,8 @@ class Config(C.Structure):
         ("born_min_z", C.c_float), ("pursuer_spawn_radius", C.c_float), ("invader_speed", C.c_float),
         ("ally_speed", C.c_float), ("ally_policy", C.c_int32), ("approach_bonus_gain", C.c_float),
         ("catch_distance", C.c_float), ("building_position", C.c_float * 3),
-        ("motor_noise", C.c_int32), ("auto_reset", C.c_int32), ("kamikaze_cone_check", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("motor_noise", C.c_int32), ("auto_reset", C.c_int32), ("kamikaze_cone_check", C.c_int32), ("stacked_obs", C.c_int32),
+        ("reserved", C.c_int32 * 4),
         ("quad", QuadParams),
     ]
 

@@ -24,6 +24,14 @@ static int calculate_rounds(int defenders, int munition) {
   return (int)ceil(root);
 }
 
+/* Level5_Task.calculate_max_rounds (threatsense/level5/components/tasks_management/tasks/level5_task.py:105-149):
+ * ceil of the positive root of R^2 + (2a - 1) R - 2 (pursuers * munition + 1) = 0, a = NUM_INVADERS */
+static int calculate_max_rounds(int pursuers, int munition, int initial_invaders) {
+  double total = (double)pursuers * (double)munition + 1.0;
+  double b = 2.0 * (double)initial_invaders - 1.0;
+  return (int)ceil((-b + sqrt(b * b + 8.0 * total)) / 2.0);
+}
+
 /* PyFlyt 0.11.1 "cf2x" (models/vehicles/cf2x/cf2x.yaml + cf2x.urdf), recorded in SURVEY.md
  * Appendix B from the public sources.  UNVERIFIED here: pyflyt is absent from this container. */
 static void cf2x_defaults(te_quad_params* q) {
@@ -103,6 +111,14 @@ TE_API int te_config_default(te_config* c, int32_t task) {
       c->ally_policy = task == TE_TASK_EXP03 ? TE_ALLY_BT : TE_ALLY_FROZEN;
       c->approach_bonus_gain = task == TE_TASK_EXP03 ? 1.0f : 10.0f;
       break;
+    case TE_TASK_LEVEL5: /* level5_task.py:76-98: the exp03 task logic with 6 wingmen, 12 invader slots, stacked observation */
+      c->n_pursuers = 6; c->munition = 20; c->n_invaders = 12;
+      c->n_rounds = calculate_max_rounds(6, 20, 12);
+      c->dome_radius = 20.0f; c->lidar_radius = 40.0f;
+      c->max_step = 300; c->pursuer_spawn_radius = 2.0f;
+      c->ally_policy = TE_ALLY_BT; c->approach_bonus_gain = 1.0f;
+      c->stacked_obs = 1;
+      break;
     default:
       return 2;
   }
@@ -114,6 +130,10 @@ TE_API int te_algorithmic_bytes_per_env_step(const te_config* c, size_t* out) {
   if (!c || !out) return 1;
   size_t D = (size_t)(c->n_pursuers + c->n_invaders);
   *out = D * 2 * 176 + 2 * 40 + 16 + ((size_t)TE_LIDAR_CHANNELS * TE_LIDAR_CELLS * 4 + 15 * 4 + 4 * 4 + 4 + 4);
+  if (c->stacked_obs) {  /* level5: 6 spheres + mask instead of 1; one ring entry written per wingman, <= 4 read */
+    size_t P = (size_t)c->n_pursuers, entry = (size_t)TE_RING_ENTRY_WORDS(D) * 4;
+    *out += (size_t)(TE_STACK_SPHERES - 1) * TE_OBS_LIDAR_WORDS * 4 + TE_STACK_SPHERES + P * entry + 4 * entry;
+  }
   return 0;
 }
 

@@ -36,6 +36,10 @@ struct Params {
   uint32_t* dstate;
   uint32_t* estate;
   int N, Npad, D;
+  // level5 (cfg.stacked_obs): observation-time snapshot planes (te_stacked.hpp SnapRows) and the snapshot ring; else null
+  uint32_t* snap;
+  uint32_t* ring;
+  int entry_words;
   unsigned long long* dbg;  // phase stamps of one block (diagnostic builds with -DTE_DEBUG_STAMPS only; else unused)
 };
 #ifdef TE_DEBUG_STAMPS
@@ -115,7 +119,7 @@ TE_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
   }
   return U4{c0, c1, c2, c3};
 }
-enum { RNG_SPAWN_INVADER = 1, RNG_SPAWN_PURSUER = 2, RNG_HIT = 3, RNG_MOTOR = 4, RNG_ACTION = 5, RNG_RESPAWN = 6 };
+enum { RNG_SPAWN_INVADER = 1, RNG_SPAWN_PURSUER = 2, RNG_HIT = 3, RNG_MOTOR = 4, RNG_ACTION = 5, RNG_RESPAWN = 6, RNG_STACK = 7 };
 // counter = { global env (low 32), purpose | slot<<8 | sub<<16 | global env (high 8)<<24, episode, index }
 TE_DEV U4 env_rng(const te_config& c, int env, uint32_t purpose, uint32_t slot, uint32_t sub, uint32_t episode,
                   uint32_t index) {

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "te_logic.hpp"
+#include "te_stacked.hpp"
 
 namespace te {
 
@@ -226,6 +227,23 @@ __global__ __launch_bounds__(256) void reset_kernel(Params p, const uint8_t* __r
   if (mask && !mask[env]) return;
   GView v{p.dstate, p.estate, p.D, p.Npad, env, p.cfg.n_pursuers};
   reset_env<FAMILY>(p.cfg, v);
+  if (p.ring)  // base_lidar.py:62-66: the step-0 broadcast resets every LIDAR buffer
+    for (int k = 0; k < p.cfg.n_pursuers * TE_RING_DEPTH; ++k) p.ring[((size_t)env * p.cfg.n_pursuers * TE_RING_DEPTH + k) * (size_t)p.entry_words] = 0u;
+}
+// te_observe_stacked: the snapshot planes of the CURRENT state (the engage/observe kernel writes them during a step)
+__global__ __launch_bounds__(256) void snapshot_kernel(Params p) {
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env >= p.N) return;
+  const GView v{p.dstate, p.estate, p.D, p.Npad, env, p.cfg.n_pursuers};
+  const SnapRows sr{p.D, p.cfg.n_pursuers};
+  for (int k = 0; k < 3; ++k) {
+    for (int s = 0; s < p.D; ++s) p.snap[(size_t)(sr.pos() + k * p.D + s) * p.Npad + env] = (uint32_t)v.gi(TE_D_OBS_POS + k, s);
+    for (int s = 0; s < sr.P; ++s) p.snap[(size_t)(sr.euler() + k * sr.P + s) * p.Npad + env] = (uint32_t)v.gi(TE_D_OBS_EULER + k, s);
+  }
+  p.snap[(size_t)sr.armed() * p.Npad + env] = armed_mask(v);
+  p.snap[(size_t)sr.step() * p.Npad + env] = (uint32_t)v.egi(TE_E_STEP);
+  p.snap[(size_t)sr.episode() * p.Npad + env] = (uint32_t)v.egi(TE_E_EPISODE);
+  p.snap[(size_t)sr.done() * p.Npad + env] = 0u;
 }
 // recompute the pending scripted commands from a freshly loaded state blob (te_set_state)
 __global__ __launch_bounds__(256) void prepare_commands_kernel(Params p) {
@@ -300,6 +318,22 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
   TE_STAMP(p, 500, 3);
   __syncthreads();
   TE_STAMP(p, 500, 4);
+  if (FAMILY == FAM_LEVEL4 && p.snap) {
+    // level5: leave what this step's stacked observation may look at for stacked_kernel, BEFORE anything respawns
+    const SnapRows sr{p.D, r.P};
+    for (int it = threadIdx.x; it < kEPB * sr.total(); it += blockDim.x) {
+      const int l = it & (kEPB - 1), w = it / kEPB;
+      uint32_t v;
+      if (w < 3 * p.D) v = sm[(r.obs_pos() + w) * kEPB + l];
+      else if (w < sr.armed()) { const int k = (w - 3 * p.D) / r.P, s = (w - 3 * p.D) - k * r.P; v = p.dstate[((size_t)(TE_D_OBS_EULER + k) * p.D + s) * p.Npad + env0 + l]; }
+      else if (w == sr.armed()) v = sm[r.anow() * kEPB + l];
+      else if (w == sr.step()) v = sm[r.sstep() * kEPB + l];
+      else if (w == sr.episode()) v = sm[r.sepis() * kEPB + l];
+      else v = sm[r.done() * kEPB + l];
+      p.snap[(size_t)w * p.Npad + env0 + l] = v;
+    }
+    __syncthreads();  // the spawn phase overwrites the obs_pos rows
+  }
   if (FAMILY == FAM_LEVEL4) {
     // spawn phase: the slots of every env that starts a new round or auto-resets, one (env, slot) per thread
     // iteration (slot-major: consecutive threads = consecutive envs).  Rare per env, but with 64 envs per
@@ -432,6 +466,7 @@ struct te_env {
   int device;
   int family;
   size_t lds_bytes;
+  size_t stack_lds_bytes = 0;  // stacked_kernel (level5)
   int n_fill_waves = 256;  // fill waves of the sub-step kernel (one per CU of an MI355X); TE_FILL_WAVES overrides
   // profiling (te_profile_begin / te_profile_end)
   std::vector<hipEvent_t> events;
@@ -477,7 +512,8 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->n_envs < 1) return fail("te_create: n_envs < 1");
   if (cfg->n_pursuers < 1 || cfg->n_invaders < 1 || D > kMaxD) return fail("te_create: need 1 <= P, 1 <= I, P + I <= 32");
   if (cfg->substeps < 1 || cfg->substeps > 255) return fail("te_create: substeps out of range");
-  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_EXP04) return fail("te_create: unknown task");
+  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_LEVEL5) return fail("te_create: unknown task");
+  if (cfg->stacked_obs && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: stacked_obs needs a level4-family task");
   if (cfg->task == TE_TASK_STAGE01 && !(cfg->n_pursuers == 2 && cfg->n_invaders == 1)) return fail("te_create: stage01 is 2 pursuers + 1 invader");
   if (cfg->lidar_radius <= 0.0f || cfg->dome_radius <= 0.0f || cfg->max_speed <= 0.0f) return fail("te_create: radii / max_speed must be positive");
   int ndev = 0;
@@ -512,6 +548,21 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     delete e;
     return fail("te_create: hipMalloc failed");
   }
+  e->p.snap = nullptr; e->p.ring = nullptr; e->p.entry_words = TE_RING_ENTRY_WORDS(D);
+  if (cfg->stacked_obs) {
+    e->stack_lds_bytes = (size_t)stack_lds_rows(D, cfg->n_pursuers) * kEPB * sizeof(uint32_t);
+    const size_t snap_bytes = (size_t)snap_words(D, cfg->n_pursuers) * e->p.Npad * 4;
+    const size_t ring_bytes = (size_t)cfg->n_envs * cfg->n_pursuers * TE_RING_DEPTH * e->p.entry_words * 4;
+    hipError_t le = hipFuncSetAttribute(reinterpret_cast<const void*>(&stacked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->stack_lds_bytes);
+    if (le != hipSuccess || hipMalloc(&e->p.snap, snap_bytes) != hipSuccess || hipMalloc(&e->p.ring, ring_bytes) != hipSuccess) {
+      if (e->p.snap) (void)hipFree(e->p.snap);
+      (void)hipFree(e->p.dstate); (void)hipFree(e->p.estate);
+      delete e;
+      return fail("te_create: stacked observation buffers (ring / snapshot / LDS) could not be set up");
+    }
+    TE_HIP(hipMemsetAsync(e->p.snap, 0, snap_bytes, nullptr));
+    TE_HIP(hipMemsetAsync(e->p.ring, 0, ring_bytes, nullptr));
+  }
   e->p.dbg = nullptr;
 #ifdef TE_DEBUG_STAMPS
   const size_t dbg_words = 64 + 16 * (size_t)(e->p.Npad / kEPB + 1);
@@ -537,6 +588,8 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
   (void)hipFree(e->p.dstate);
   (void)hipFree(e->p.estate);
+  if (e->p.snap) (void)hipFree(e->p.snap);
+  if (e->p.ring) (void)hipFree(e->p.ring);
   if (e->p.dbg) (void)hipFree(e->p.dbg);
   delete e;
 }
@@ -563,12 +616,16 @@ __attribute__((visibility("default"))) int te_observe(te_env* e, float* obs_lida
   return 0;
 }
 
-__attribute__((visibility("default"))) int te_step(te_env* e, const float* actions, float* obs_lidar, float* obs_inertial,
-                                                   float* obs_last_action, float* reward, uint8_t* done, int32_t* info,
-                                                   float* terminal_lidar, float* terminal_inertial, float* terminal_last_action,
-                                                   void* stream) {
+// one env.step of every env.  `obs_lidar` is the buffer whose background the sub-step kernel's fill waves stream:
+// [N,3,13,26] for te_step, [N,6,3,13,26] (`lidar_words_per_env` = 6084) for te_step_stacked, which also passes `stack`.
+static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t lidar_words_per_env, float* obs_inertial,
+                     float* obs_last_action, float* reward, uint8_t* done, int32_t* info, float* terminal_lidar,
+                     float* terminal_inertial, float* terminal_last_action, const StackOut* stack, void* stream) {
   if (!e) return fail("te_step: null env");
   if (!actions || !reward || !done || !info) return fail("te_step: actions, reward, done and info are required");
+  if ((e->p.ring != nullptr) != (stack != nullptr))
+    return fail(stack ? "te_step_stacked: this te_env was created without cfg.stacked_obs"
+                      : "te_step: this te_env keeps a snapshot ring (cfg.stacked_obs); step it with te_step_stacked");
   if (((uintptr_t)actions & 15) || ((uintptr_t)info & 15) || (obs_lidar && ((uintptr_t)obs_lidar & 15)) ||
       (obs_last_action && ((uintptr_t)obs_last_action & 15)) || (terminal_last_action && ((uintptr_t)terminal_last_action & 15)))
     return fail("te_step: actions, info, obs_lidar and the last_action buffers must be 16-byte aligned");
@@ -582,7 +639,7 @@ __attribute__((visibility("default"))) int te_step(te_env* e, const float* actio
   // LIDAR background: N*1014 floats = quads float4 (+ <4 tail floats).  The drone waves write one float4 per
   // lane; the rest is split evenly over the fill waves.
   FillJob fill{nullptr, 0u, 0u};
-  const size_t n_floats = (size_t)p.N * TE_OBS_LIDAR_WORDS;
+  const size_t n_floats = (size_t)p.N * lidar_words_per_env;
   if (obs_lidar) {
     const size_t quads = n_floats >> 2, first = (size_t)waves * 64;
     if (quads > first && quads < (1ull << 32)) {
@@ -604,12 +661,57 @@ __attribute__((visibility("default"))) int te_step(te_env* e, const float* actio
   });
   if (prof) TE_HIP(hipEventRecord(e->events[e->prof_used + 1], st));
   const int b2 = (p.N + kEPB - 1) / kEPB;
-  StepOut o{reward, done, info, ObsOut{obs_lidar, obs_inertial, obs_last_action},
-            ObsOut{terminal_lidar, terminal_inertial, terminal_last_action}};
+  // the engage/observe kernel patches the agent's own sphere only in the classic layout; in stacked mode all LIDAR
+  // output comes from stacked_kernel
+  StepOut o{reward, done, info, ObsOut{stack ? nullptr : obs_lidar, obs_inertial, obs_last_action},
+            ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}};
   launch_by_family(e->family, [&](auto fam) {
     hipLaunchKernelGGL((engage_observe_kernel<decltype(fam)::value>), dim3(b2), dim3(256), e->lds_bytes, st, p, actions, o);
   });
+  if (stack) {
+    StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 1};
+    hipLaunchKernelGGL(stacked_kernel, dim3(b2), dim3(256), e->stack_lds_bytes, st, sp, *stack);
+  }
   if (prof) { TE_HIP(hipEventRecord(e->events[e->prof_used + 2], st)); e->prof_used += 3; }
+  TE_HIP(hipGetLastError());
+  return 0;
+}
+
+__attribute__((visibility("default"))) int te_step(te_env* e, const float* actions, float* obs_lidar, float* obs_inertial,
+                                                   float* obs_last_action, float* reward, uint8_t* done, int32_t* info,
+                                                   float* terminal_lidar, float* terminal_inertial, float* terminal_last_action,
+                                                   void* stream) {
+  return step_impl(e, actions, obs_lidar, TE_OBS_LIDAR_WORDS, obs_inertial, obs_last_action, reward, done, info, terminal_lidar,
+                   terminal_inertial, terminal_last_action, nullptr, stream);
+}
+
+__attribute__((visibility("default"))) int te_step_stacked(te_env* e, const float* actions, float* obs_stacked, uint8_t* obs_mask,
+                                                           float* obs_inertial, float* obs_last_action, float* reward, uint8_t* done,
+                                                           int32_t* info, float* terminal_stacked, uint8_t* terminal_mask,
+                                                           float* terminal_inertial, float* terminal_last_action, void* stream) {
+  if (!obs_stacked || !obs_mask) return fail("te_step_stacked: obs_stacked and obs_mask are required");
+  if (((uintptr_t)obs_stacked & 15) || (terminal_stacked && ((uintptr_t)terminal_stacked & 15)))
+    return fail("te_step_stacked: the stacked buffers must be 16-byte aligned");
+  if ((terminal_stacked == nullptr) != (terminal_mask == nullptr)) return fail("te_step_stacked: terminal_stacked and terminal_mask go together");
+  const StackOut so{obs_stacked, obs_mask, terminal_stacked, terminal_mask};
+  return step_impl(e, actions, obs_stacked, TE_OBS_STACKED_WORDS, obs_inertial, obs_last_action, reward, done, info, nullptr,
+                   terminal_inertial, terminal_last_action, &so, stream);
+}
+
+__attribute__((visibility("default"))) int te_observe_stacked(te_env* e, float* obs_stacked, uint8_t* obs_mask, float* obs_inertial,
+                                                              float* obs_last_action, void* stream) {
+  if (!e) return fail("te_observe_stacked: null env");
+  if (!e->p.ring) return fail("te_observe_stacked: this te_env was created without cfg.stacked_obs");
+  if (!obs_stacked || !obs_mask || ((uintptr_t)obs_stacked & 15)) return fail("te_observe_stacked: obs_stacked (16-byte aligned) and obs_mask are required");
+  DeviceGuard guard(e->device);
+  hipStream_t st = (hipStream_t)stream;
+  const Params& p = e->p;
+  const int blocks = (p.N + kEPB - 1) / kEPB;
+  hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, obs_stacked, (size_t)p.N * TE_OBS_STACKED_WORDS);
+  hipLaunchKernelGGL(snapshot_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(observe_kernel, dim3(blocks), dim3(256), e->lds_bytes, st, p, ObsOut{nullptr, obs_inertial, obs_last_action});
+  StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 0};
+  hipLaunchKernelGGL(stacked_kernel, dim3(blocks), dim3(256), e->stack_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
   TE_HIP(hipGetLastError());
   return 0;
 }
@@ -623,9 +725,12 @@ __attribute__((visibility("default"))) int te_random_actions(te_env* e, float* a
   return 0;
 }
 
+static size_t ring_words(const te_env* e) {  // level5: the snapshot ring rides at the end of the state blob
+  return e->p.ring ? (size_t)e->p.N * e->p.cfg.n_pursuers * TE_RING_DEPTH * (size_t)e->p.entry_words : 0;
+}
 __attribute__((visibility("default"))) int te_state_words(const te_env* e, size_t* out_words) {
   if (!e || !out_words) return fail("te_state_words: null argument");
-  *out_words = (size_t)e->p.N * ((size_t)e->p.D * TE_DRONE_WORDS + TE_ENV_WORDS);
+  *out_words = (size_t)e->p.N * ((size_t)e->p.D * TE_DRONE_WORDS + TE_ENV_WORDS) + ring_words(e);
   return 0;
 }
 
@@ -635,6 +740,8 @@ __attribute__((visibility("default"))) int te_get_state(te_env* e, void* dst_dev
   if (!dst_device || words != need) return fail("te_get_state: buffer must hold exactly te_state_words() words");
   DeviceGuard guard(e->device);
   hipLaunchKernelGGL(planes_to_blob, dim3(1024), dim3(256), 0, (hipStream_t)stream, e->p, (uint32_t*)dst_device);
+  if (e->p.ring)
+    TE_HIP(hipMemcpyAsync((uint32_t*)dst_device + (need - ring_words(e)), e->p.ring, ring_words(e) * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   TE_HIP(hipGetLastError());
   return 0;
 }
@@ -645,6 +752,8 @@ __attribute__((visibility("default"))) int te_set_state(te_env* e, const void* s
   if (!src_device || words != need) return fail("te_set_state: buffer must hold exactly te_state_words() words");
   DeviceGuard guard(e->device);
   hipLaunchKernelGGL(blob_to_planes, dim3(1024), dim3(256), 0, (hipStream_t)stream, e->p, (const uint32_t*)src_device);
+  if (e->p.ring)
+    TE_HIP(hipMemcpyAsync(e->p.ring, (const uint32_t*)src_device + (need - ring_words(e)), ring_words(e) * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (e->family == FAM_LEVEL4)
     hipLaunchKernelGGL(prepare_commands_kernel, dim3((e->p.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->p);
   TE_HIP(hipGetLastError());

@@ -55,9 +55,12 @@ struct Rows {
   TE_DEV int prevalid() const { return done() + 1; }        // 1   : distance / zone rows still valid after the logic
   TE_DEV int task() const { return prevalid() + 1; }        // 1   : level4 spawn work left to the block: round | reset << 8
   TE_DEV int smask() const { return task() + 1; }           // 1   : bit s = drone s armed when the block was staged
-  TE_DEV int total() const { return smask() + 1; }
+  TE_DEV int anow() const { return smask() + 1; }           // 1   : bit s = drone s armed after the engagement (observation time)
+  TE_DEV int sstep() const { return smask() + 2; }          // 1   : RL step of this observation (the env record may be reset after it)
+  TE_DEV int sepis() const { return smask() + 3; }          // 1   : episode of this observation
+  TE_DEV int total() const { return sepis() + 1; }
 };
-__host__ __device__ inline int lds_rows(int D, int P) { return 6 * D + 2 * P + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 7; }
+__host__ __device__ inline int lds_rows(int D, int P) { return 6 * D + 2 * P + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 10; }
 
 struct SView {
   GView g; uint32_t* sm; int lane; Rows r;
@@ -623,6 +626,7 @@ template <int FAMILY, class FinishFn>
 TE_DEV void emit_and_finish(const te_config& c, const SView& v, int step, bool term, uint32_t armed_now, const StepOut& o, FinishFn finish) {
   const bool to_terminal = term && c.auto_reset;
   v.sm[v.at(v.r.done())] = to_terminal ? 1u : 0u;
+  v.sm[v.at(v.r.anow())] = armed_now; v.sm[v.at(v.r.sstep())] = (uint32_t)step; v.sm[v.at(v.r.sepis())] = (uint32_t)v.egi(TE_E_EPISODE);
   v.sm[v.at(v.r.hitmask())] = resolve_hits(v, armed_now);  // compute_observation happens before on_step_end
   TE_LSTAMP(12);
   if (to_terminal) {  // SB3 VecEnv auto-reset: the terminal observation goes aside (rare: straight from this lane)

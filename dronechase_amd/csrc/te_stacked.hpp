@@ -1,0 +1,358 @@
+// te_stacked.hpp — level5: the per-wingman snapshot ring and the FusedLIDAR stacked observation of the agent
+// (reference: core/entities/quadcopters/components/sensors/fused_lidar.py:73-109,143-262,293-326;
+//  components/lidar_buffer.py:10-157; components/lidar_math.py:186-345; threatsense/level5/level5_envrionment.py:312-351).
+//
+// Canonical clock: the ring entry of env-step s holds a wingman's IMU pose of step s and the kept
+// features of its own sphere built from the poses of step s; at step t the entry of step t has age 1
+// (normalized_delta 0.1, as in the own sphere) and an entry of age a is the one of step t - a + 1.
+//
+// The engage/observe kernel leaves a *snapshot* of what the observation of this step may look at (IMU positions of
+// all drones, IMU attitude of the wingmen, who is armed after the engagement, step / episode / done) in a few
+// planes BEFORE it respawns anything; stacked_kernel (one 256-thread block per 64 envs) then
+//   (1) pushes every armed wingman's entry into the ring          one (env, other drone) item per thread, per wingman
+//   (2) draws the agent's neighbourhood (Philox)                  one lane per env
+//   (3) re-projects each chosen snapshot into the agent's frame   one (env, neighbour) per thread, farther wins
+//   (4) patches own + neighbour spheres into the [N,6,3,13,26] buffer that the sub-step kernel's fill waves
+//       already set to ones, writes the validity mask, and clears the ring of auto-reset envs.
+#pragma once
+#include "te_logic.hpp"
+
+namespace te {
+
+// snapshot planes written by the engage/observe kernel: word w of env e at snap[w * Npad + e]
+struct SnapRows {
+  int D, P;
+  TE_DEV int pos() const { return 0; }                 // 3*D : IMU positions, word-major, slot-minor
+  TE_DEV int euler() const { return 3 * D; }           // 3*P : IMU attitude of the wingmen
+  TE_DEV int armed() const { return 3 * D + 3 * P; }   // bit s = drone s armed after the engagement
+  TE_DEV int step() const { return armed() + 1; }      // RL step of the observation (before any auto-reset)
+  TE_DEV int episode() const { return armed() + 2; }
+  TE_DEV int done() const { return armed() + 3; }      // the env auto-resets in this step
+  TE_DEV int total() const { return armed() + 4; }
+};
+__host__ __device__ inline int snap_words(int D, int P) { return 3 * D + 3 * P + 4; }
+
+struct StackOut { float* stacked; uint8_t* mask; float* t_stacked; uint8_t* t_mask; };
+
+// LDS rows (kEPB words each) of stacked_kernel
+struct StackRows {
+  int D, P;
+  TE_DEV int F() const { return D - 1; }                      // most features one entry can keep
+  TE_DEV int pos() const { return 0; }                        // 3*D
+  TE_DEV int quat() const { return 3 * D; }                   // 4*P : quaternion rebuilt from the IMU attitude (imu.py:38)
+  TE_DEV int armed() const { return quat() + 4 * P; }         // 1
+  TE_DEV int step() const { return armed() + 1; }
+  TE_DEV int episode() const { return armed() + 2; }
+  TE_DEV int done() const { return armed() + 3; }
+  TE_DEV int feat() const { return armed() + 4; }             // 4*D : r_hat, theta, phi, cell of drone j seen from wingman p
+  TE_DEV int own_n() const { return feat() + 4 * D; }         // 1   : kept features of the agent's own sphere
+  TE_DEV int own_k() const { return own_n() + 1; }            // 2*F : cell | type << 16, r_hat
+  TE_DEV int dn() const { return own_k() + 2 * F(); }         // 1   : neighbours drawn
+  TE_DEV int dwho() const { return dn() + 1; }                // 1   : 4 x 8 bits
+  TE_DEV int dage() const { return dn() + 2; }                // 1   : 4 x 8 bits
+  TE_DEV int dperm() const { return dn() + 3; }               // 1   : 6 x 4 bits, out[i] = stack[perm[i]]
+  TE_DEV int nb_n() const { return dn() + 4; }                // 4   : kept features of neighbour k, or 0xFFFFFFFF = no sphere
+  TE_DEV int nb_k() const { return nb_n() + 4; }              // 4 * 2*F
+  TE_DEV int opos() const { return nb_k() + 8 * F(); }        // 5   : output position of own / neighbour k (or 0xFF)
+  TE_DEV int total() const { return opos() + 5; }
+};
+__host__ __device__ inline int stack_lds_rows(int D, int P) { return 3 * D + 4 * P + 4 + 4 * D + 1 + 2 * (D - 1) + 4 + 4 + 8 * (D - 1) + 5; }
+
+TE_DEV V3 rotate_by(Q4 q, V3 v) { return mul(rotation(q), v); }  // pybullet rotateVector
+TE_DEV Q4 inverse_of(Q4 q) {  // LidarMath._invert_quaternion (lidar_math.py:40-51)
+  const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  return Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2};
+}
+// cartesian -> (r_hat, theta, phi, cell)  (lidar_math.py:24-34,93-96,128-137)
+TE_DEV void spherical_of(const te_config& c, V3 v, float& rhat, float& theta, float& phi, int& cell) {
+  const float r = norm(v);
+  theta = 0.0f; phi = 0.0f;
+  if (r != 0.0f) { theta = acosf(clampf(v.z / r, -1.0f, 1.0f)); phi = atan2f(v.y, v.x); }
+  rhat = clampf(r / c.lidar_radius, 0.0f, 1.0f);
+  const int ti = min(max((int)(theta / kPi * (float)TE_LIDAR_NTHETA), 0), TE_LIDAR_NTHETA - 1);
+  const int pi = min(max((int)((phi + kPi) / (2.0f * kPi) * (float)TE_LIDAR_NPHI), 0), TE_LIDAR_NPHI - 1);
+  cell = ti * TE_LIDAR_NPHI + pi;
+}
+TE_DEV uint32_t* ring_entry_ptr(uint32_t* ring, int entry_words, int P, size_t env, int p, int step) {
+  return ring + ((env * (size_t)P + (size_t)p) * TE_RING_DEPTH + (size_t)(step % TE_RING_DEPTH)) * (size_t)entry_words;
+}
+// the ring is written and read by different waves of one block: read around the (write-through, not coherent) L1
+TE_DEV uint32_t load_fresh(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+
+// (2) FusedLIDAR.bootstrap / randomize_stack draws; must match oracle/te_oracle.c:draw_stack word for word
+TE_DEV void draw_stack(const te_config& c, int env, uint32_t episode, uint32_t step, uint32_t armed_pursuers, int P, int& n,
+                       uint32_t& who, uint32_t& age, uint32_t& perm) {
+  uint32_t w[16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const U4 r = env_rng(c, env, RNG_STACK, 0u, (uint32_t)k, episode, step);
+    w[4 * k] = r.x; w[4 * k + 1] = r.y; w[4 * k + 2] = r.z; w[4 * k + 3] = r.w;
+  }
+  uint32_t cand = armed_pursuers;  // candidates as a bit set; "position i of the array" = i-th set bit still unused
+  const int nc = __popc(cand);
+  const int want = 1 + (int)(((uint64_t)w[0] * 4u) >> 32);
+  n = want < nc ? want : nc;
+  // partial Fisher-Yates over the candidates in slot order, on an explicit small array (nc <= 32)
+  uint8_t arr[kMaxD];
+  int m = 0;
+  for (int p = 0; p < P; ++p) if ((cand >> p) & 1u) arr[m++] = (uint8_t)p;
+  who = 0u; age = 0u;
+  for (int i = 0; i < 4; ++i) {
+    if (i >= n) break;
+    const int j = i + (int)(((uint64_t)w[1 + i] * (uint32_t)(nc - i)) >> 32);
+    const uint8_t t = arr[i]; arr[i] = arr[j]; arr[j] = t;
+    who |= (uint32_t)arr[i] << (8 * i);
+    age |= (uint32_t)(1 + (int)(((uint64_t)w[5 + i] * (uint32_t)(TE_RING_DEPTH - 1)) >> 32)) << (8 * i);
+  }
+  uint8_t pm[TE_STACK_SPHERES];
+  for (int i = 0; i < TE_STACK_SPHERES; ++i) pm[i] = (uint8_t)i;
+  for (int i = TE_STACK_SPHERES - 1; i >= 1; --i) {
+    const int j = (int)(((uint64_t)w[9 + (TE_STACK_SPHERES - 1 - i)] * (uint32_t)(i + 1)) >> 32);
+    const uint8_t t = pm[i]; pm[i] = pm[j]; pm[j] = t;
+  }
+  perm = 0u;
+  for (int i = 0; i < TE_STACK_SPHERES; ++i) perm |= (uint32_t)pm[i] << (4 * i);
+}
+
+struct StackParams {
+  te_config cfg;
+  const uint32_t* snap;  // snapshot planes
+  uint32_t* ring;
+  int N, Npad, D, entry_words;
+  int push;              // 1: te_step_stacked (push this step's entries, clear the ring of auto-reset envs); 0: te_observe_stacked
+};
+
+__global__ __launch_bounds__(256) void stacked_kernel(StackParams p, StackOut o) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+  const te_config& c = p.cfg;
+  const int D = p.D, P = c.n_pursuers;
+  const StackRows r{D, P};
+  const SnapRows sr{D, P};
+  const int env0 = blockIdx.x * kEPB, nvalid = min(kEPB, p.N - env0);
+  const int tid = threadIdx.x, lane = tid & (kEPB - 1);
+  auto row = [&](int rr, int l) -> uint32_t& { return sm[rr * kEPB + l]; };
+  auto rowf = [&](int rr, int l) { return __uint_as_float(sm[rr * kEPB + l]); };
+  // ---- stage the snapshot (coalesced: planes are env-fastest)
+  for (int it = tid; it < kEPB * sr.total(); it += blockDim.x) {
+    const int l = it & (kEPB - 1), w = it / kEPB;
+    const uint32_t v = p.snap[(size_t)w * p.Npad + env0 + l];
+    if (w < 3 * D) row(r.pos() + w, l) = v;
+    else if (w < sr.armed()) row(r.feat() + (w - 3 * D), l) = v;  // euler parked in the feature rows until the quaternions are built
+    else row(r.armed() + (w - sr.armed()), l) = v;
+  }
+  __syncthreads();
+  for (int it = tid; it < kEPB * P; it += blockDim.x) {  // quaternion of every wingman, rounded to float32 as the snapshot does
+    const int l = it & (kEPB - 1), pp = it / kEPB;
+    const Q4 q = quat_of_euler(V3{rowf(r.feat() + 0 * P + pp, l), rowf(r.feat() + 1 * P + pp, l), rowf(r.feat() + 2 * P + pp, l)});
+    row(r.quat() + 0 * P + pp, l) = __float_as_uint(q.x); row(r.quat() + 1 * P + pp, l) = __float_as_uint(q.y);
+    row(r.quat() + 2 * P + pp, l) = __float_as_uint(q.z); row(r.quat() + 3 * P + pp, l) = __float_as_uint(q.w);
+  }
+  if (tid < kEPB) { row(r.own_n(), tid) = 0u; }
+  __syncthreads();
+  auto pos_of = [&](int s, int l) { return V3{rowf(r.pos() + 0 * D + s, l), rowf(r.pos() + 1 * D + s, l), rowf(r.pos() + 2 * D + s, l)}; };
+  auto quat_of = [&](int pp, int l) { return Q4{rowf(r.quat() + 0 * P + pp, l), rowf(r.quat() + 1 * P + pp, l), rowf(r.quat() + 2 * P + pp, l), rowf(r.quat() + 3 * P + pp, l)}; };
+
+  // ---- (1) FusedLIDAR.update_data of every armed wingman -> ring entry of this step
+  if (p.push) {
+    for (int pp = 0; pp < P; ++pp) {
+      for (int it = tid; it < kEPB * D; it += blockDim.x) {
+        const int l = it & (kEPB - 1), j = it / kEPB;
+        const uint32_t A = row(r.armed(), l);
+        if (j == pp || !((A >> j) & 1u) || !((A >> pp) & 1u)) { row(r.feat() + 3 * D + j, l) = 0xFFFFFFFFu; continue; }
+        const V3 local = rotate_by(inverse_of(quat_of(pp, l)), sub(pos_of(j, l), pos_of(pp, l)));
+        float rhat, th, ph; int cell;
+        spherical_of(c, local, rhat, th, ph, cell);
+        row(r.feat() + 0 * D + j, l) = __float_as_uint(rhat); row(r.feat() + 1 * D + j, l) = __float_as_uint(th);
+        row(r.feat() + 2 * D + j, l) = __float_as_uint(ph); row(r.feat() + 3 * D + j, l) = (uint32_t)cell;
+      }
+      __syncthreads();
+      if (tid < kEPB && tid < nvalid && ((row(r.armed(), tid) >> pp) & 1u)) {  // closer wins per cell, in slot order (lidar_math.py:262-311)
+        const int l = tid, step = (int)row(r.step(), l);
+        // working list in the (still unused) neighbour rows: 5 words per kept feature = cell, r_hat, theta, phi, meta
+        const int wk = r.nb_k();
+        int n = 0;
+        for (int j = 0; j < D; ++j) {
+          const uint32_t cell = row(r.feat() + 3 * D + j, l);
+          if (cell == 0xFFFFFFFFu) continue;
+          const float rhat = rowf(r.feat() + 0 * D + j, l);
+          int at = -1;
+          for (int k = 0; k < n; ++k) if (row(wk + 5 * k, l) == cell) at = k;
+          if (at < 0) { if (!(rhat < 1.0f)) continue; at = n++; }  // an empty cell holds 1.0: strict '<'
+          else if (!(rhat < rowf(wk + 5 * at + 1, l))) continue;
+          row(wk + 5 * at, l) = cell; row(wk + 5 * at + 1, l) = __float_as_uint(rhat);
+          row(wk + 5 * at + 2, l) = row(r.feat() + 1 * D + j, l); row(wk + 5 * at + 3, l) = row(r.feat() + 2 * D + j, l);
+          row(wk + 5 * at + 4, l) = (uint32_t)(j < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) | ((uint32_t)j << 8);
+        }
+        uint32_t* ent = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), pp, step);
+        const V3 me = pos_of(pp, l); const Q4 q = quat_of(pp, l);
+        ent[0] = (uint32_t)step; ent[1] = (uint32_t)n;
+        ent[2] = __float_as_uint(me.x); ent[3] = __float_as_uint(me.y); ent[4] = __float_as_uint(me.z);
+        ent[5] = __float_as_uint(q.x); ent[6] = __float_as_uint(q.y); ent[7] = __float_as_uint(q.z); ent[8] = __float_as_uint(q.w);
+        ent[9] = ent[10] = ent[11] = 0u;
+        for (int k = 0; k < D - 1; ++k) {
+          uint4 f = make_uint4(0u, 0u, 0u, 0u);
+          if (k < n) {
+            f = make_uint4(row(wk + 5 * k + 1, l), row(wk + 5 * k + 2, l), row(wk + 5 * k + 3, l), row(wk + 5 * k + 4, l));
+            if (pp == 0) {  // the agent keeps (cell, type, r_hat) of its own sphere for the patch phase
+              row(r.own_k() + 2 * k, l) = row(wk + 5 * k, l) | ((f.w & 0xFFu) << 16); row(r.own_k() + 2 * k + 1, l) = f.x;
+            }
+          }
+          *reinterpret_cast<uint4*>(ent + TE_RING_HEADER_WORDS + 4 * k) = f;
+        }
+        if (pp == 0) row(r.own_n(), l) = (uint32_t)n;
+      }
+      __syncthreads();
+    }
+  }
+  // ---- (2) the agent's own snapshot and its draws
+  if (tid < kEPB) {
+    const int l = tid;
+    uint32_t n = 0u, who = 0u, age = 0u, perm = 0u;
+    const int step = (int)row(r.step(), l);
+    bool own_ok = l < nvalid && step >= 1;
+    if (own_ok) {
+      const uint32_t* own = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), 0, step);
+      if (p.push) own_ok = (row(r.armed(), l) & 1u) != 0u;  // pushed above iff the agent is armed
+      else {  // te_observe_stacked: the own sphere comes back out of the ring
+        own_ok = (int)load_fresh(own) == step;
+        if (own_ok) {
+          const int cnt = (int)load_fresh(own + 1);
+          for (int k = 0; k < cnt; ++k) {
+            const uint32_t* f = own + TE_RING_HEADER_WORDS + 4 * k;
+            float rhat = __uint_as_float(load_fresh(f)), th = __uint_as_float(load_fresh(f + 1)), ph = __uint_as_float(load_fresh(f + 2));
+            const int ti = min(max((int)(th / kPi * (float)TE_LIDAR_NTHETA), 0), TE_LIDAR_NTHETA - 1);
+            const int pi = min(max((int)((ph + kPi) / (2.0f * kPi) * (float)TE_LIDAR_NPHI), 0), TE_LIDAR_NPHI - 1);
+            row(r.own_k() + 2 * k, l) = (uint32_t)(ti * TE_LIDAR_NPHI + pi) | ((load_fresh(f + 3) & 0xFFu) << 16);
+            row(r.own_k() + 2 * k + 1, l) = __float_as_uint(rhat);
+          }
+          row(r.own_n(), l) = (uint32_t)cnt;
+        }
+      }
+    }
+    if (own_ok) {
+      int nn;
+      draw_stack(c, env0 + l, row(r.episode(), l), (uint32_t)step, row(r.armed(), l) & ((1u << P) - 1u), P, nn, who, age, perm);
+      n = (uint32_t)nn;
+    } else row(r.own_n(), l) = 0xFFFFFFFFu;  // _build_valid_spheres returns [] without an own snapshot (fused_lidar.py:91-96)
+    row(r.dn(), l) = n; row(r.dwho(), l) = who; row(r.dage(), l) = age; row(r.dperm(), l) = perm;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- (3) neighbour k of env l: transform_features + add_features(invert) (lidar_math.py:186-345), sequentially
+  {
+    const int l = lane, k = tid >> 6;
+    uint32_t count = 0xFFFFFFFFu;
+    if (l < nvalid && k < (int)row(r.dn(), l)) {
+      const int step = (int)row(r.step(), l);
+      const int q = (int)((row(r.dwho(), l) >> (8 * k)) & 0xFFu), a = (int)((row(r.dage(), l) >> (8 * k)) & 0xFFu);
+      const int s = step - (a - 1);
+      const uint32_t* nb = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), q, s > 0 ? s : 0);
+      if (s >= 1 && (int)load_fresh(nb) == s) {  // get_snapshot -> None otherwise (lidar_buffer.py:152-154)
+        const uint32_t* own = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), 0, step);
+        const V3 pn{__uint_as_float(load_fresh(nb + 2)), __uint_as_float(load_fresh(nb + 3)), __uint_as_float(load_fresh(nb + 4))};
+        const Q4 qn{__uint_as_float(load_fresh(nb + 5)), __uint_as_float(load_fresh(nb + 6)), __uint_as_float(load_fresh(nb + 7)), __uint_as_float(load_fresh(nb + 8))};
+        const V3 po{__uint_as_float(load_fresh(own + 2)), __uint_as_float(load_fresh(own + 3)), __uint_as_float(load_fresh(own + 4))};
+        const Q4 qo{__uint_as_float(load_fresh(own + 5)), __uint_as_float(load_fresh(own + 6)), __uint_as_float(load_fresh(own + 7)), __uint_as_float(load_fresh(own + 8))};
+        const M3 Rn = rotation(qn), Ro = rotation(inverse_of(qo));
+        const int cnt = (int)load_fresh(nb + 1);
+        const int base = r.nb_k() + k * 2 * r.F();
+        count = 0u;
+        for (int f = 0; f < cnt; ++f) {
+          const uint32_t* ff = nb + TE_RING_HEADER_WORDS + 4 * f;
+          const uint32_t meta = load_fresh(ff + 3);
+          if ((int)((meta >> 8) & 0xFFu) == 0) continue;  // synthetic echo of the agent itself (lidar_math.py:228-232)
+          const float R = __uint_as_float(load_fresh(ff)) * c.lidar_radius, th = __uint_as_float(load_fresh(ff + 1)), ph = __uint_as_float(load_fresh(ff + 2));
+          float st, ct, sp, cp;
+          sincosf(th, &st, &ct); sincosf(ph, &sp, &cp);
+          const V3 cart{R * st * cp, R * st * sp, R * ct};                          // spherical_to_cartesian (lidar_math.py:16-22)
+          const V3 glob = mul(Rn, cart);
+          const V3 loc = mul(Ro, V3{glob.x + pn.x - po.x, glob.y + pn.y - po.y, glob.z + pn.z - po.z});
+          float rhat, t2, p2; int cell;
+          spherical_of(c, loc, rhat, t2, p2, cell);
+          int at = -1;
+          for (uint32_t j = 0; j < count; ++j) if ((row(base + 2 * j, l) & 0xFFFFu) == (uint32_t)cell) at = (int)j;
+          bool put = true;
+          if (at >= 0) { const float cur = rowf(base + 2 * at + 1, l); put = cur < 1.0f ? rhat > cur : true; }
+          else at = (int)count++;
+          if (put) { row(base + 2 * at, l) = (uint32_t)cell | ((meta & 0xFFu) << 16); row(base + 2 * at + 1, l) = __float_as_uint(rhat); }
+        }
+      }
+    }
+    if (k < 4) row(r.nb_n() + k, l) = count;
+  }
+  __syncthreads();
+  // ---- (4a) stack order -> output positions and the validity mask (fused_lidar.py:293-326,246-262)
+  if (tid < kEPB && tid < nvalid) {
+    const int l = tid;
+    const bool done = row(r.done(), l) != 0u;
+    uint8_t* M = (done ? o.t_mask : o.mask);
+    const bool any = row(r.own_n(), l) != 0xFFFFFFFFu;
+    // stack index of own = 0, of valid neighbour k = 1 + (valid neighbours before k)
+    int sidx[5]; int nv = 0;
+    sidx[0] = any ? nv++ : -1;
+    for (int k = 0; k < 4; ++k) sidx[1 + k] = (any && row(r.nb_n() + k, l) != 0xFFFFFFFFu) ? nv++ : -1;
+    const uint32_t perm = row(r.dperm(), l);
+    for (int s = 0; s < 5; ++s) {
+      uint32_t at = 0xFFu;
+      if (sidx[s] >= 0) for (int i = 0; i < TE_STACK_SPHERES; ++i) if ((int)((perm >> (4 * i)) & 0xFu) == sidx[s]) at = (uint32_t)i;
+      row(r.opos() + s, l) = at;
+    }
+    if (M) for (int i = 0; i < TE_STACK_SPHERES; ++i) M[(size_t)(env0 + l) * TE_STACK_SPHERES + i] = (any && (int)((perm >> (4 * i)) & 0xFu) < nv) ? 1 : 0;
+    if (done && o.mask) for (int i = 0; i < TE_STACK_SPHERES; ++i) o.mask[(size_t)(env0 + l) * TE_STACK_SPHERES + i] = 0;  // reset observation
+  }
+  // ---- (4b) terminal tiles of auto-reset envs are not pre-filled: ones first (rare, block-uniform test)
+  const bool lane_done = tid < kEPB && tid < nvalid && row(r.done(), tid) != 0u;
+  if (__syncthreads_or(lane_done ? 1 : 0)) {
+    if (o.t_stacked)
+      for (int l = 0; l < nvalid; ++l) {
+        if (!row(r.done(), l)) continue;
+        float* base = o.t_stacked + (size_t)(env0 + l) * TE_OBS_STACKED_WORDS;
+        for (int e = tid; e < TE_OBS_STACKED_WORDS; e += blockDim.x) base[e] = 1.0f;
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // ---- (4c) patches
+  auto dst_of = [&](int l, int sphere_slot) -> float* {
+    const uint32_t at = row(r.opos() + sphere_slot, l);
+    float* basep = row(r.done(), l) ? o.t_stacked : o.stacked;
+    if (at == 0xFFu || !basep) return nullptr;
+    return basep + (size_t)(env0 + l) * TE_OBS_STACKED_WORDS + (size_t)at * TE_OBS_LIDAR_WORDS;
+  };
+  for (int it = tid; it < kEPB * (D - 1); it += blockDim.x) {  // own sphere: time = 1/10 (perception_snapshot.py:36-37)
+    const int l = it & (kEPB - 1), f = it / kEPB;
+    if (l >= nvalid) continue;
+    const uint32_t n = row(r.own_n(), l);
+    if (n == 0xFFFFFFFFu || f >= (int)n) continue;
+    float* d = dst_of(l, 0);
+    if (!d) continue;
+    const uint32_t w = row(r.own_k() + 2 * f, l);
+    d += (w & 0xFFFFu);
+    d[0] = rowf(r.own_k() + 2 * f + 1, l); d[TE_LIDAR_CELLS] = (float)(w >> 16) / 5.0f; d[2 * TE_LIDAR_CELLS] = 0.1f;
+  }
+  {
+    const int l = lane, k = tid >> 6;
+    const uint32_t n = (l < nvalid && k < 4) ? row(r.nb_n() + k, l) : 0xFFFFFFFFu;
+    if (n != 0xFFFFFFFFu) {
+      float* d0 = dst_of(l, 1 + k);
+      if (d0) {
+        const float tnorm = (float)((row(r.dage(), l) >> (8 * k)) & 0xFFu) / (float)TE_RING_DEPTH;  // normalized_delta of the snapshot
+        const int base = r.nb_k() + k * 2 * r.F();
+        for (uint32_t f = 0; f < n; ++f) {
+          const uint32_t w = row(base + 2 * f, l);
+          float* d = d0 + (w & 0xFFFFu);
+          d[0] = rowf(base + 2 * f + 1, l); d[TE_LIDAR_CELLS] = (float)(w >> 16) / 5.0f; d[2 * TE_LIDAR_CELLS] = tnorm;
+        }
+      }
+    }
+  }
+  // ---- (4d) buffer reset of auto-reset envs (base_lidar.py:62-66: step 0 resets every LIDAR buffer)
+  if (p.push)
+    for (int it = tid; it < kEPB * P * TE_RING_DEPTH; it += blockDim.x) {
+      const int l = it & (kEPB - 1), e = it / kEPB;
+      if (l >= nvalid || !row(r.done(), l)) continue;
+      p.ring[(((size_t)(env0 + l) * P) * TE_RING_DEPTH + (size_t)e) * (size_t)p.entry_words] = 0u;
+    }
+}
+
+}  // namespace te

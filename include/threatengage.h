@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TE_ABI_VERSION 1
+#define TE_ABI_VERSION 2
 
 /* ---- tasks (reference env class each one mirrors) ----------------------- */
 enum {
@@ -39,7 +39,9 @@ enum {
   TE_TASK_STAGE02 = 2, /* level3/pyflyt_level3_environment_v2.py + components/stages.py (apps stage02) */
   TE_TASK_EXP02 = 3,   /* level4/exp02_vFinal_environment.py + tasks/exp02_vFinal_task.py */
   TE_TASK_EXP03 = 4,   /* level4/exp03_vFinal_environment.py + tasks/exp03_vFinal_task.py (apps stage03) */
-  TE_TASK_EXP04 = 5    /* level4/exp04_vFinal_environment.py (ally frozen, x10 approach bonus) */
+  TE_TASK_EXP04 = 5,   /* level4/exp04_vFinal_environment.py (ally frozen, x10 approach bonus) */
+  TE_TASK_LEVEL5 = 6   /* threatsense/level5/level5_envrionment.py + tasks/level5_task.py: the exp03 task with 6 pursuers,
+                          12 invaders and the FusedLIDAR stacked-sphere observation (te_step_stacked) */
 };
 
 /* ally (pursuer slots >= 1) policy */
@@ -61,6 +63,18 @@ enum { TE_TYPE_LOITERINGMUNITION = 1, TE_TYPE_QUADCOPTER = 2, TE_TYPE_LOYALWINGM
 #define TE_OBS_INERTIAL_WORDS 15 /* pos3 vel3 att3 rate3 gun3 (exp03_vFinal_environment.py:200-228) */
 #define TE_OBS_ACTION_WORDS 4
 #define TE_INFO_WORDS 4 /* agent_kills, allies_kills, deads, current_wave (exp03_vFinal_task.py:571-578) */
+
+/* ---- FusedLIDAR stacked observation (level5; fused_lidar.py:73-109,223-326, lidar_buffer.py:10-157) ----
+ * own sphere + up to n_neighbors_max re-projected neighbour spheres, padded to TE_STACK_SPHERES, shuffled. */
+#define TE_RING_DEPTH 10        /* snapshots kept per wingman (base_lidar.py:40: max_buffer_size=10) */
+#define TE_STACK_NEIGHBORS_MIN 1
+#define TE_STACK_NEIGHBORS_MAX 5 /* n ~ random.choice(range(1, 5)) = 1..4 neighbours (fused_lidar.py:77) */
+#define TE_STACK_SPHERES 6      /* n_neighbors_max + 1 (fused_lidar.py:305) */
+#define TE_OBS_STACKED_WORDS (TE_STACK_SPHERES * TE_OBS_LIDAR_WORDS) /* 6084 floats = 24 336 B per env */
+/* one ring entry = one wingman's PerceptionSnapshot of one step: 12 header words + 4 per kept feature */
+#define TE_RING_HEADER_WORDS 12 /* [0] i32 step stamp (0 = empty)  [1] i32 n_features  [2..4] position  [5..8] quaternion xyzw  [9..11] 0 */
+#define TE_RING_FEATURE_WORDS 4 /* r_hat, theta, phi (own frame of the publisher), i32 entity type | publisher slot << 8 */
+#define TE_RING_ENTRY_WORDS(D) (TE_RING_HEADER_WORDS + TE_RING_FEATURE_WORDS * ((D) - 1))
 
 /* ---- quadrotor model: PyFlyt 0.11.1 QuadX "cf2x" + Bullet free body ------
  * The sources of these numbers (pyflyt 0.11.1, pybullet 3.2.7; poetry.lock:1412-1440)
@@ -127,7 +141,8 @@ typedef struct te_config {
   int32_t auto_reset;     /* 1: VecEnv semantics (reset inside step when done) */
   int32_t kamikaze_cone_check; /* 0: air-combat-only navigator (_is_building_path_clear == False, used by every
                                   vFinal task); 1: cone test of loitering_munition_navigator.py:78-87 */
-  int32_t reserved[5];
+  int32_t stacked_obs;    /* 1: keep the per-wingman snapshot ring and serve te_step_stacked (level5) */
+  int32_t reserved[4];
 
   te_quad_params quad;
 } te_config;
@@ -211,6 +226,19 @@ int te_step(te_env* env, const float* actions, float* obs_lidar, float* obs_iner
             float* obs_last_action, float* reward, uint8_t* done, int32_t* info,
             float* terminal_lidar, float* terminal_inertial, float* terminal_last_action,
             void* stream);
+
+/* Level5 (cfg.stacked_obs = 1): the same step with the FusedLIDAR stacked observation of the agent instead of
+ * its own sphere (threatsense/level5/level5_envrionment.py:312-351; fused_lidar.py:73-109,223-326):
+ *   obs_stacked [N,6,3,13,26] f32 — own sphere, 1..4 re-projected neighbour snapshots of random age (farther
+ *                wins), padded with empty spheres, then shuffled;   obs_mask [N,6] u8 — 1 = a valid sphere.
+ * Every armed wingman's snapshot (pose + the features of its own sphere) is pushed into a 10-deep ring per step;
+ * the ring is part of the state blob.  terminal_* as in te_step.  te_observe_stacked is te_observe's counterpart
+ * (after a reset every sphere is empty and every mask byte 0: there is no snapshot yet). */
+int te_step_stacked(te_env* env, const float* actions, float* obs_stacked, uint8_t* obs_mask, float* obs_inertial,
+                    float* obs_last_action, float* reward, uint8_t* done, int32_t* info, float* terminal_stacked,
+                    uint8_t* terminal_mask, float* terminal_inertial, float* terminal_last_action, void* stream);
+int te_observe_stacked(te_env* env, float* obs_stacked, uint8_t* obs_mask, float* obs_inertial, float* obs_last_action,
+                       void* stream);
 
 /* Synthetic random-action generator of the throughput harness
  * (apps/threatengage_runner/interactive/analyse.py:55-59): dir ~ U(-1,1)^3, mag ~ U(0,1),

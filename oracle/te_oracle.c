@@ -70,6 +70,13 @@ typedef struct ote_env {
   ote_envrec* envs;  /* [N] */
   real* margin;      /* [N] min |value - threshold| over ALL discrete decisions of the last step */
   real* margin_state; /* [N] same, restricted to decisions that change state or done (not reward-only ones) */
+  /* level5 (cfg.stacked_obs): per-wingman snapshot ring, same word layout as the product's state blob
+   * (include/threatengage.h TE_RING_*): ring[((e * P + p) * TE_RING_DEPTH + r) * entry_words] */
+  uint32_t* ring;
+  int entry_words;
+  real* margin_stack; /* [N] smallest angular distance (rad) of any binned feature to a LIDAR cell boundary, last step */
+  /* outputs of the step in flight (set by ote_step_stacked, NULL otherwise) */
+  float* out_stacked; uint8_t* out_mask; float* out_t_stacked; uint8_t* out_t_mask;
 } ote_env;
 
 /* ------------------------------------------------------------------------- */
@@ -79,7 +86,7 @@ typedef struct ote_env {
 /* are keyed (seed; global env, purpose, episode, sub-counter) instead.                         */
 /* ------------------------------------------------------------------------- */
 enum { OTE_RNG_SPAWN_INVADER = 1, OTE_RNG_SPAWN_PURSUER = 2, OTE_RNG_HIT = 3, OTE_RNG_MOTOR = 4,
-       OTE_RNG_ACTION = 5, OTE_RNG_RESPAWN = 6 };
+       OTE_RNG_ACTION = 5, OTE_RNG_RESPAWN = 6, OTE_RNG_STACK = 7 };
 
 static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
@@ -748,6 +755,171 @@ OTE_API void ote_own_sphere_from_poses(int D, int P, const double* pos, const do
   own_sphere(&c, dr, D, own, sphere);
 }
 
+/* ------------------------------------------------------------------------- */
+/* level5: snapshot ring + FusedLIDAR stacked observation                                        */
+/* (fused_lidar.py:73-109,143-262,293-326; lidar_buffer.py:10-157; lidar_math.py:186-345)        */
+/* Canonical clock: the entry of env-step s holds the wingman's IMU pose of step s  */
+/* and the kept features of its own sphere built from the poses of step s; at step t the entry of */
+/* step t has age 1 (normalized_delta 0.1, as in the own sphere), an entry of age a is step t-a+1.*/
+/* ------------------------------------------------------------------------- */
+static float u2f(uint32_t w) { float f; memcpy(&f, &w, 4); return f; }
+static uint32_t f2u(float f) { uint32_t w; memcpy(&w, &f, 4); return w; }
+static uint32_t* ring_entry(const ote_env* E, int e, int p, int step) {
+  return E->ring + (((size_t)e * E->cfg.n_pursuers + p) * TE_RING_DEPTH + (size_t)(step % TE_RING_DEPTH)) * E->entry_words;
+}
+static void ring_clear_env(ote_env* E, int e) {
+  if (!E->ring) return;
+  memset(E->ring + (size_t)e * E->cfg.n_pursuers * TE_RING_DEPTH * E->entry_words, 0,
+         (size_t)E->cfg.n_pursuers * TE_RING_DEPTH * E->entry_words * sizeof(uint32_t));
+}
+static real cell_margin(real theta, real phi) {
+  real ft = theta / OTE_PI * (real)TE_LIDAR_NTHETA, fp = (phi + OTE_PI) / ((real)2 * OTE_PI) * (real)TE_LIDAR_NPHI;
+  real mt = fabs(ft - floor(ft + (real)0.5)) * OTE_PI / (real)TE_LIDAR_NTHETA;
+  real mp = fabs(fp - floor(fp + (real)0.5)) * (real)2 * OTE_PI / (real)TE_LIDAR_NPHI;
+  return mt < mp ? mt : mp;
+}
+/* FusedLIDAR.update_data of wingman `own` (fused_lidar.py:143-217) -> its ring entry of this step: the kept
+ * feature of every cell (closer wins, lidar_math.py:262-311) as (r_hat, theta, phi, type, publisher). */
+static void ring_push(ote_env* E, int e, int own, int step) {
+  const te_config* c = &E->cfg;
+  const int D = E->D;
+  const ote_drone* dr = &E->drones[(size_t)e * D];
+  uint32_t* ent = ring_entry(E, e, own, step);
+  memset(ent, 0, (size_t)E->entry_words * sizeof(uint32_t));
+  real q[4];
+  quat_from_euler(dr[own].obs_euler, q);
+  for (int k = 0; k < 4; ++k) q[k] = (real)(float)q[k];
+  ent[0] = (uint32_t)step;
+  for (int k = 0; k < 3; ++k) ent[2 + k] = f2u((float)dr[own].obs_pos[k]);
+  for (int k = 0; k < 4; ++k) ent[5 + k] = f2u((float)q[k]);
+  int n = 0, cells[OTE_MAX_DRONES];
+  for (int j = 0; j < D; ++j) {
+    if (j == own || !dr[j].armed) continue;
+    real local[3], sph[3];
+    reframe_origin(dr[j].obs_pos, dr[own].obs_pos, q, local);
+    cartesian_to_spherical(local, sph);
+    real rhat = clampr(sph[0] / (real)c->lidar_radius, (real)0, (real)1);
+    real m = cell_margin(sph[1], sph[2]);
+    if (m < E->margin_stack[e]) E->margin_stack[e] = m;
+    int cell = theta_index(sph[1]) * TE_LIDAR_NPHI + phi_index(sph[2]);
+    int type = j < c->n_pursuers ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION;
+    int at = -1;
+    for (int k = 0; k < n; ++k) if (cells[k] == cell) at = k;
+    if (at < 0) {
+      if (!(rhat < (real)1)) continue; /* an empty cell holds 1.0: strict '<' */
+      at = n++; cells[at] = cell;
+    } else if (!(rhat < (real)u2f(ent[TE_RING_HEADER_WORDS + 4 * at]))) continue;
+    uint32_t* f = ent + TE_RING_HEADER_WORDS + 4 * at;
+    f[0] = f2u((float)rhat); f[1] = f2u((float)sph[1]); f[2] = f2u((float)sph[2]);
+    f[3] = (uint32_t)type | ((uint32_t)j << 8);
+  }
+  ent[1] = (uint32_t)n;
+}
+static void sphere_ones(float* sp) { for (int i = 0; i < TE_OBS_LIDAR_WORDS; ++i) sp[i] = 1.0f; }
+/* sphere of a ring entry seen from its own publisher (= that wingman's own sphere of that step) */
+static void entry_own_sphere(const uint32_t* ent, float* sp) {
+  sphere_ones(sp);
+  for (int k = 0; k < (int)ent[1]; ++k) {
+    const uint32_t* f = ent + TE_RING_HEADER_WORDS + 4 * k;
+    int cell = theta_index((real)u2f(f[1])) * TE_LIDAR_NPHI + phi_index((real)u2f(f[2]));
+    sp[cell] = u2f(f[0]);
+    sp[TE_LIDAR_CELLS + cell] = (float)((real)(f[3] & 0xFFu) / (real)5);
+    sp[2 * TE_LIDAR_CELLS + cell] = (float)((real)1 / (real)10);
+  }
+}
+/* LidarMath.neighbor_sphere_from_new_frame (lidar_math.py:327-345) = transform_features (:186-260) +
+ * add_features with the inverted criterion (:248-259,314-325): farther wins unless the cell is still empty. */
+static void neighbor_sphere(ote_env* E, int e, const uint32_t* nb, const uint32_t* own, int own_slot, int age, float* sp) {
+  const te_config* c = &E->cfg;
+  sphere_ones(sp);
+  real pn[3], qn[4], po[3], qo[4];
+  for (int k = 0; k < 3; ++k) { pn[k] = (real)u2f(nb[2 + k]); po[k] = (real)u2f(own[2 + k]); }
+  for (int k = 0; k < 4; ++k) { qn[k] = (real)u2f(nb[5 + k]); qo[k] = (real)u2f(own[5 + k]); }
+  real n2 = qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3];
+  real qi[4] = {-qo[0] / n2, -qo[1] / n2, -qo[2] / n2, qo[3] / n2};
+  for (int k = 0; k < (int)nb[1]; ++k) {
+    const uint32_t* f = nb + TE_RING_HEADER_WORDS + 4 * k;
+    if ((int)(f[3] >> 8) == own_slot) continue; /* synthetic echo of self (lidar_math.py:228-232) */
+    real s3[3] = {(real)u2f(f[0]) * (real)c->lidar_radius, (real)u2f(f[1]), (real)u2f(f[2])}, cart[3], glob[3], rel[3], loc[3], sph[3];
+    spherical_to_cartesian(s3, cart);
+    rotate_vector(qn, cart, glob);
+    for (int i = 0; i < 3; ++i) rel[i] = glob[i] + pn[i] - po[i];
+    rotate_vector(qi, rel, loc);
+    cartesian_to_spherical(loc, sph);
+    real rhat = clampr(sph[0] / (real)c->lidar_radius, (real)0, (real)1);
+    real m = cell_margin(sph[1], sph[2]);
+    if (m < E->margin_stack[e]) E->margin_stack[e] = m;
+    int cell = theta_index(sph[1]) * TE_LIDAR_NPHI + phi_index(sph[2]);
+    real cur = (real)sp[cell];
+    if (cur < (real)1 ? rhat > cur : 1) {
+      sp[cell] = (float)rhat;
+      sp[TE_LIDAR_CELLS + cell] = (float)((real)(f[3] & 0xFFu) / (real)5);
+      sp[2 * TE_LIDAR_CELLS + cell] = (float)((real)age / (real)TE_RING_DEPTH);
+    }
+  }
+}
+/* the draws of FusedLIDAR.bootstrap / randomize_stack (fused_lidar.py:73-81,246-262; lidar_buffer.py:110-157):
+ * n ~ U{1..4}; n distinct armed wingmen (the agent included) without replacement; an age ~ U{1..9} each; a
+ * uniform permutation of the six (sphere, valid) pairs.  16 Philox words keyed (STACK, slot 0, sub 0..3,
+ * episode, step); an integer in [0, k) is (word * k) >> 32. */
+typedef struct { int n, who[4], age[4], perm[TE_STACK_SPHERES]; } stack_draws;
+static void draw_stack(const ote_env* E, int e, int episode, int step, uint32_t armed_pursuers, stack_draws* d) {
+  uint32_t w[16];
+  for (int k = 0; k < 4; ++k) ote_rng(E, e, OTE_RNG_STACK, 0, (uint32_t)k, (uint32_t)episode, (uint32_t)step, w + 4 * k);
+  int cand[OTE_MAX_DRONES], nc = 0;
+  for (int p = 0; p < E->cfg.n_pursuers; ++p) if ((armed_pursuers >> p) & 1u) cand[nc++] = p;
+  int want = 1 + (int)(((uint64_t)w[0] * 4u) >> 32);
+  d->n = want < nc ? want : nc;
+  for (int i = 0; i < d->n; ++i) { /* random.sample: partial Fisher-Yates over the candidates in slot order */
+    int j = i + (int)(((uint64_t)w[1 + i] * (uint32_t)(nc - i)) >> 32);
+    int t = cand[i]; cand[i] = cand[j]; cand[j] = t;
+    d->who[i] = cand[i];
+    d->age[i] = 1 + (int)(((uint64_t)w[5 + i] * (uint32_t)(TE_RING_DEPTH - 1)) >> 32);
+  }
+  for (int i = 0; i < TE_STACK_SPHERES; ++i) d->perm[i] = i;
+  for (int i = TE_STACK_SPHERES - 1; i >= 1; --i) { /* random.shuffle */
+    int j = (int)(((uint64_t)w[9 + (TE_STACK_SPHERES - 1 - i)] * (uint32_t)(i + 1)) >> 32);
+    int t = d->perm[i]; d->perm[i] = d->perm[j]; d->perm[j] = t;
+  }
+}
+OTE_API void ote_stack_draws(const te_config* cfg, int env_local, int episode, int step, uint32_t armed_pursuers, int32_t* out /*15*/) {
+  ote_env E; memset(&E, 0, sizeof E); E.cfg = *cfg;
+  stack_draws d; memset(&d, 0, sizeof d);
+  draw_stack(&E, env_local, episode, step, armed_pursuers, &d);
+  out[0] = d.n;
+  for (int i = 0; i < 4; ++i) { out[1 + i] = i < d.n ? d.who[i] : -1; out[5 + i] = i < d.n ? d.age[i] : 0; }
+  for (int i = 0; i < TE_STACK_SPHERES; ++i) out[9 + i] = d.perm[i];
+}
+/* FusedLIDAR.read_data for the agent (slot 0): [own, neighbours...] -> pad -> shuffle.  out[i] = stack[perm[i]]. */
+static void stacked_observation(ote_env* E, int e, int step, uint32_t armed_now, float* out, uint8_t* mask) {
+  const te_config* c = &E->cfg;
+  const ote_envrec* er = &E->envs[e];
+  float stack[TE_STACK_SPHERES][TE_OBS_LIDAR_WORDS];
+  uint8_t valid[TE_STACK_SPHERES];
+  int nv = 0;
+  memset(valid, 0, sizeof valid);
+  const uint32_t* own = step >= 1 ? ring_entry(E, e, 0, step) : NULL;
+  if (own && (int)own[0] == step) { /* _build_valid_spheres: nothing at all without an own snapshot (:91-96) */
+    entry_own_sphere(own, stack[nv]); valid[nv++] = 1;
+    stack_draws d;
+    draw_stack(E, e, er->episode, step, armed_now & ((1u << c->n_pursuers) - 1u), &d);
+    for (int i = 0; i < d.n; ++i) {
+      int s = step - (d.age[i] - 1);
+      if (s < 1) continue;
+      const uint32_t* nb = ring_entry(E, e, d.who[i], s);
+      if ((int)nb[0] != s) continue; /* get_snapshot -> None (lidar_buffer.py:152-154) */
+      neighbor_sphere(E, e, nb, own, 0, d.age[i], stack[nv]); valid[nv++] = 1;
+    }
+    for (int i = nv; i < TE_STACK_SPHERES; ++i) sphere_ones(stack[i]);
+    for (int i = 0; i < TE_STACK_SPHERES; ++i) {
+      memcpy(out + (size_t)i * TE_OBS_LIDAR_WORDS, stack[d.perm[i]], sizeof stack[0]);
+      mask[i] = valid[d.perm[i]];
+    }
+  } else {
+    for (int i = 0; i < TE_STACK_SPHERES; ++i) { sphere_ones(out + (size_t)i * TE_OBS_LIDAR_WORDS); mask[i] = 0; }
+  }
+}
+
 /* normalize_inertial_data (level4/components/utils/normalization.py:6-30,61-110) + gun state +
  * last action (exp03_vFinal_environment.py:200-228) */
 static void inertial_obs(const te_config* c, const ote_drone* d, int step, int max_mun, float out[TE_OBS_INERTIAL_WORDS]) {
@@ -834,6 +1006,7 @@ static void level4_refresh_snapshot(ote_env* E, int e) {
 }
 /* Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146, exp03_vFinal_task.py:255-274) */
 static void level4_reset_env(ote_env* E, int e) {
+  ring_clear_env(E, e); /* buffer_step_broadcast with step 0 resets every LIDAR buffer (base_lidar.py:62-66) */
   const te_config* c = &E->cfg;
   ote_drone* dr = &E->drones[(size_t)e * E->D];
   ote_envrec* er = &E->envs[e];
@@ -1021,6 +1194,17 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   if (L) own_sphere(c, dr, D, 0, L);
   if (In) inertial_obs(c, &dr[0], step, max_munition_of(c, 0), In);
   if (La) for (int k = 0; k < 4; ++k) La[k] = (float)er->last_action[k];
+  if (c->stacked_obs) { /* level5_envrionment.py:312-351: every wingman's update_lidar, then the agent's stack */
+    E->margin_stack[e] = (real)1e30;
+    const uint32_t armed_now = armed_mask(dr, D);
+    for (int p = 0; p < P; ++p) if (dr[p].armed) ring_push(E, e, p, step);
+    if (E->out_stacked) {
+      const int aside = to_terminal && E->out_t_stacked && E->out_t_mask;
+      float* So = (aside ? E->out_t_stacked : E->out_stacked) + (size_t)e * TE_OBS_STACKED_WORDS;
+      uint8_t* Mo = (aside ? E->out_t_mask : E->out_mask) + (size_t)e * TE_STACK_SPHERES;
+      stacked_observation(E, e, step, armed_now, So, Mo);
+    }
+  }
 
   /* (7) task.on_step_end (:321-333) */
   if (!term && !all_rounds_over && armed_invaders == 0 && armed_pursuers > 0) {
@@ -1032,6 +1216,10 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   /* (8) VecEnv auto-reset */
   if (term && c->auto_reset) {
     level4_reset_env(E, e);
+    if (c->stacked_obs && E->out_stacked) { /* no snapshot yet: six empty spheres, nothing valid */
+      for (int i = 0; i < TE_OBS_STACKED_WORDS; ++i) E->out_stacked[(size_t)e * TE_OBS_STACKED_WORDS + i] = 1.0f;
+      for (int i = 0; i < TE_STACK_SPHERES; ++i) E->out_mask[(size_t)e * TE_STACK_SPHERES + i] = 0;
+    }
     if (lidar) for (int i = 0; i < TE_OBS_LIDAR_WORDS; ++i) lidar[i] = 1.0f;
     if (inertial) inertial_obs(c, &dr[0], 0, max_munition_of(c, 0), inertial);
     if (last_action) for (int k = 0; k < 4; ++k) last_action[k] = 0.0f;
@@ -1331,13 +1519,17 @@ OTE_API ote_env* ote_create(const te_config* cfg) {
   E->envs = (ote_envrec*)calloc((size_t)cfg->n_envs, sizeof(ote_envrec));
   E->margin = (real*)calloc((size_t)cfg->n_envs, sizeof(real));
   E->margin_state = (real*)calloc((size_t)cfg->n_envs, sizeof(real));
+  E->margin_stack = (real*)calloc((size_t)cfg->n_envs, sizeof(real));
+  E->entry_words = TE_RING_ENTRY_WORDS(D);
+  if (cfg->stacked_obs)
+    E->ring = (uint32_t*)calloc((size_t)cfg->n_envs * cfg->n_pursuers * TE_RING_DEPTH * E->entry_words, sizeof(uint32_t));
   for (size_t i = 0; i < (size_t)cfg->n_envs * D; ++i) E->drones[i].quat[3] = 1;
   for (int e = 0; e < cfg->n_envs; ++e) reset_env(E, e);
   return E;
 }
 OTE_API void ote_destroy(ote_env* E) {
   if (!E) return;
-  free(E->drones); free(E->envs); free(E->margin); free(E->margin_state); free(E);
+  free(E->drones); free(E->envs); free(E->margin); free(E->margin_state); free(E->margin_stack); free(E->ring); free(E);
 }
 OTE_API int ote_real_bytes(void) { return (int)sizeof(real); }
 OTE_API int ote_reset(ote_env* E, const uint8_t* mask) {
@@ -1383,6 +1575,29 @@ OTE_API int ote_step(ote_env* E, const float* actions, float* lidar, float* iner
   }
   return 0;
 }
+/* level5: te_step_stacked / te_observe_stacked */
+OTE_API int ote_step_stacked(ote_env* E, const float* actions, float* stacked, uint8_t* mask, float* inertial, float* last_action,
+                             float* reward, uint8_t* done, int32_t* info, float* t_stacked, uint8_t* t_mask, float* t_inertial,
+                             float* t_last_action, int threads) {
+  if (!E->cfg.stacked_obs || !stacked || !mask) return 1;
+  E->out_stacked = stacked; E->out_mask = mask; E->out_t_stacked = t_stacked; E->out_t_mask = t_mask;
+  int rc = ote_step(E, actions, NULL, inertial, last_action, reward, done, info, NULL, t_inertial, t_last_action, threads);
+  E->out_stacked = NULL; E->out_mask = NULL; E->out_t_stacked = NULL; E->out_t_mask = NULL;
+  return rc;
+}
+OTE_API int ote_observe_stacked(ote_env* E, float* stacked, uint8_t* mask, float* inertial, float* last_action) {
+  if (!E->cfg.stacked_obs || !stacked || !mask) return 1;
+  for (int e = 0; e < E->cfg.n_envs; ++e) {
+    const ote_drone* dr = &E->drones[(size_t)e * E->D];
+    stacked_observation(E, e, E->envs[e].step, armed_mask(dr, E->D), stacked + (size_t)e * TE_OBS_STACKED_WORDS,
+                        mask + (size_t)e * TE_STACK_SPHERES);
+  }
+  return ote_observe(E, NULL, inertial, last_action);
+}
+OTE_API int ote_stack_margins(const ote_env* E, double* out) {
+  for (int e = 0; e < E->cfg.n_envs; ++e) out[e] = (double)E->margin_stack[e];
+  return 0;
+}
 OTE_API int ote_margins(const ote_env* E, double* out) {
   for (int e = 0; e < E->cfg.n_envs; ++e) out[e] = (double)E->margin[e];
   return 0;
@@ -1411,8 +1626,12 @@ static void put_f(uint32_t* w, int at, const real* v, int n) {
 static void get_f(const uint32_t* w, int at, real* v, int n) {
   for (int i = 0; i < n; ++i) { float f; memcpy(&f, &w[at + i], 4); v[i] = (real)f; }
 }
+static size_t ring_words(const ote_env* E) {
+  return E->ring ? (size_t)E->cfg.n_envs * E->cfg.n_pursuers * TE_RING_DEPTH * E->entry_words : 0;
+}
+/* drone records, env records, then (level5) the snapshot ring */
 OTE_API size_t ote_state_words(const ote_env* E) {
-  return (size_t)E->cfg.n_envs * ((size_t)E->D * TE_DRONE_WORDS + TE_ENV_WORDS);
+  return (size_t)E->cfg.n_envs * ((size_t)E->D * TE_DRONE_WORDS + TE_ENV_WORDS) + ring_words(E);
 }
 OTE_API int ote_get_state(const ote_env* E, uint32_t* dst) {
   const size_t ND = (size_t)E->cfg.n_envs * E->D;
@@ -1442,6 +1661,7 @@ OTE_API int ote_get_state(const ote_env* E, uint32_t* dst) {
     w[TE_E_DEADS] = (uint32_t)r->deads; w[TE_E_SNAP_MASK] = r->snap_mask; w[TE_E_EPISODE] = (uint32_t)r->episode;
     put_f(w, TE_E_LAST_ACTION, r->last_action, 4); put_f(w, TE_E_PREV_SNAP_MIN, &r->prev_snap_min, 1);
   }
+  if (E->ring) memcpy(base + (size_t)E->cfg.n_envs * TE_ENV_WORDS, E->ring, ring_words(E) * sizeof(uint32_t));
   return 0;
 }
 OTE_API int ote_set_state(ote_env* E, const uint32_t* src) {
@@ -1471,6 +1691,7 @@ OTE_API int ote_set_state(ote_env* E, const uint32_t* src) {
     r->deads = (int32_t)w[TE_E_DEADS]; r->snap_mask = w[TE_E_SNAP_MASK]; r->episode = (int32_t)w[TE_E_EPISODE];
     get_f(w, TE_E_LAST_ACTION, r->last_action, 4); get_f(w, TE_E_PREV_SNAP_MIN, &r->prev_snap_min, 1);
   }
+  if (E->ring) memcpy(E->ring, base + (size_t)E->cfg.n_envs * TE_ENV_WORDS, ring_words(E) * sizeof(uint32_t));
   return 0;
 }
 

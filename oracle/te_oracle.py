@@ -40,6 +40,10 @@ def lib(precision: str = "f64") -> C.CDLL:
         L.ote_observe.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         L.ote_step.argtypes = [C.c_void_p] + [C.c_void_p] * 10 + [C.c_int]
         L.ote_margins.argtypes = [C.c_void_p, C.c_void_p]
+        L.ote_stack_margins.argtypes = [C.c_void_p, C.c_void_p]
+        L.ote_step_stacked.argtypes = [C.c_void_p] + [C.c_void_p] * 12 + [C.c_int]
+        L.ote_observe_stacked.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.ote_stack_draws.argtypes = [C.POINTER(K.Config), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
         L.ote_state_margins.argtypes = [C.c_void_p, C.c_void_p]
         L.ote_random_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
         L.te_config_default.argtypes = [C.POINTER(K.Config), C.c_int32]
@@ -87,6 +91,11 @@ class OracleEnv:
         self.reward = np.empty(N, np.float32)
         self.done = np.empty(N, np.uint8)
         self.info = np.empty((N, 4), np.int32)
+        if cfg.stacked_obs:  # level5
+            self.stacked = np.empty((N, K.STACK_SPHERES, K.LIDAR_CHANNELS, K.LIDAR_NTHETA, K.LIDAR_NPHI), np.float32)
+            self.mask = np.empty((N, K.STACK_SPHERES), np.uint8)
+            self.t_stacked = np.zeros_like(self.stacked)
+            self.t_mask = np.zeros_like(self.mask)
 
     def close(self):
         if self.h:
@@ -115,6 +124,32 @@ class OracleEnv:
         self.L.ote_step(self.h, _p(a), _p(self.lidar), _p(self.inertial), _p(self.last_action), _p(self.reward),
                         _p(self.done), _p(self.info), _p(t[0]), _p(t[1]), _p(t[2]), self.threads)
         return self.lidar, self.inertial, self.last_action, self.reward, self.done, self.info
+
+    # level5 ---------------------------------------------------------------------------------
+    def observe_stacked(self):
+        self.L.ote_observe_stacked(self.h, _p(self.stacked), _p(self.mask), _p(self.inertial), _p(self.last_action))
+        return self.stacked, self.mask, self.inertial, self.last_action
+
+    def step_stacked(self, actions: np.ndarray, terminal: bool = True):
+        a = np.ascontiguousarray(actions, np.float32)
+        assert a.shape == (self.N, 4)
+        t = (self.t_stacked, self.t_mask, self.t_inertial, self.t_last_action) if terminal else (None,) * 4
+        rc = self.L.ote_step_stacked(self.h, _p(a), _p(self.stacked), _p(self.mask), _p(self.inertial), _p(self.last_action),
+                                     _p(self.reward), _p(self.done), _p(self.info), _p(t[0]), _p(t[1]), _p(t[2]), _p(t[3]),
+                                     self.threads)
+        assert rc == 0
+        return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
+
+    def stack_margins(self) -> np.ndarray:
+        """Smallest angular distance (rad) of any feature binned during the last step to a LIDAR cell boundary."""
+        out = np.empty(self.N, np.float64)
+        self.L.ote_stack_margins(self.h, _p(out))
+        return out
+
+    def ring(self, words: Optional[np.ndarray] = None) -> np.ndarray:
+        w = self.get_state() if words is None else words
+        base = self.N * (self.D * K.DRONE_WORDS + K.ENV_WORDS)
+        return w[base:].reshape(self.N, self.cfg.n_pursuers, K.RING_DEPTH, K.ring_entry_words(self.D))
 
     def margins(self) -> np.ndarray:
         out = np.empty(self.N, np.float64)
@@ -152,7 +187,8 @@ class OracleEnv:
 
     def envrecs(self, words: Optional[np.ndarray] = None) -> np.ndarray:
         w = self.get_state() if words is None else words
-        return w[self.N * self.D * K.DRONE_WORDS:].reshape(self.N, K.ENV_WORDS)
+        base = self.N * self.D * K.DRONE_WORDS
+        return w[base: base + self.N * K.ENV_WORDS].reshape(self.N, K.ENV_WORDS)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -264,3 +300,12 @@ def fly(cfg, mode, setpoint, n_substeps, pos0, precision="f64"):
     lib(precision).ote_fly(C.byref(cfg), C.c_int(mode), _p(sp), C.c_int(n_substeps), _p(p0), _p(pos), _p(vel), _p(eul),
                            _p(thr))
     return pos, vel, eul, thr
+
+
+def stack_draws(cfg: K.Config, env_local: int, episode: int, step: int, armed_pursuers: int) -> dict:
+    """The random choices of one stacked observation: n, the chosen wingmen, their ages, the shuffle."""
+    out = np.zeros(15, np.int32)
+    lib("f64").ote_stack_draws(C.byref(cfg), env_local, episode, step, armed_pursuers, _p(out))
+    n = int(out[0])
+    return {"n": n, "who": out[1:1 + n].tolist(), "age": out[5:5 + n].tolist(), "perm": out[9:15].tolist()}
+
