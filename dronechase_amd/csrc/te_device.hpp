@@ -17,8 +17,11 @@
 namespace te {
 
 // extra per-drone planes that are not part of the public state blob
-enum { TE_X_CMD = TE_DRONE_WORDS, /* 3: velocity command vx,vy,vz of a scripted ALLY for the next step */
-       TE_X_WORDS = 3 };
+enum { TE_X_CMD = TE_DRONE_WORDS,     /* 3: velocity command vx,vy,vz of a scripted ALLY for the next step */
+       TE_X_REF = TE_DRONE_WORDS + 3, /* 3: a PURSUER's IMU position as the last engage/observe launch (or reset) left it: what the
+                                         invaders' navigators steer at.  Not TE_D_OBS_POS itself: the pursuers' waves overwrite that
+                                         at the end of the very sub-step launch in which the invaders' waves read it */
+       TE_X_WORDS = 6 };
 
 // constants of the sub-step loop derived from te_config.  Computed ONCE on the host (te_create) and passed
 // by value in the kernel arguments, so they live in SGPRs: gfx950 has no scalar float ALU, and deriving

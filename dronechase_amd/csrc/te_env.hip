@@ -56,7 +56,8 @@ struct FillJob { float* lidar; uint32_t total_quads; uint32_t n_fill_waves; };
 // what kamikaze_update() reads of the other drones, through the wave's buffer resource
 struct NavView {
   const SlotLane& P; int Pn;
-  TE_DEV float gf(int w, int s) const { return P.lf_slot(w, s); }
+  // kamikaze_update() asks for a pursuer's TE_D_OBS_POS: serve the stable copy (see TE_X_REF)
+  TE_DEV float gf(int w, int s) const { return P.lf_slot(TE_X_REF + (w - TE_D_OBS_POS), s); }
 };
 
 template <int FAMILY, bool NOISE, bool FILL>
@@ -353,13 +354,20 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
     // epilogue split by wave: wave 3 prepares the allies' commands of the next step, one (env, ally) item per
     // thread iteration, while waves 0..2 write the inertial / last_action rows
     if (threadIdx.x < 192) emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, 192);
-    else
+    else {
+      for (int it = threadIdx.x - 192; it < kEPB * r.P; it += 64) {  // the invaders' reference of every pursuer (post-spawn)
+        const int l = it & (kEPB - 1), s = it / kEPB;
+        if (l >= nvalid) continue;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p.dstate[((size_t)(TE_X_REF + k) * p.D + s) * p.Npad + env0 + l] = sm[(r.obs_pos() + k * p.D + s) * kEPB + l];
+      }
       for (int it = threadIdx.x - 192; it < kEPB * (r.P - 1); it += 64) {
         const int l = it & (kEPB - 1), s = 1 + it / kEPB;
         if (l >= nvalid) continue;
         SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + l, r.P}, sm, l, r, p.D, r.P, env0 + l, sm[r.prevalid() * kEPB + l] != 0u};
         prepare_slot(p.cfg, v, s);
       }
+    }
   } else {
     emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, blockDim.x);
   }

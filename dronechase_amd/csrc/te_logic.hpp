@@ -309,7 +309,13 @@ template <class V> TE_DEV void prepare_slot(const te_config& c, const V& v, int 
   }
   v.sf(TE_X_CMD + 0, s, out[0]); v.sf(TE_X_CMD + 1, s, out[1]); v.sf(TE_X_CMD + 2, s, out[2]);
 }
+// the pursuers' positions the invaders will steer at during the next sub-step launch (TE_X_REF)
+template <class V> TE_DEV void publish_pursuer_ref(const V& v, int s) {
+  v.sf(TE_X_REF + 0, s, v.gf(TE_D_OBS_POS + 0, s)); v.sf(TE_X_REF + 1, s, v.gf(TE_D_OBS_POS + 1, s));
+  v.sf(TE_X_REF + 2, s, v.gf(TE_D_OBS_POS + 2, s));
+}
 template <class V> TE_DEV void prepare_level4_commands(const te_config& c, const V& v) {
+  for (int s = 0; s < c.n_pursuers; ++s) publish_pursuer_ref(v, s);
   for (int s = 1; s < c.n_pursuers; ++s) prepare_slot(c, v, s);
 }
 

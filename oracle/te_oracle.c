@@ -772,6 +772,23 @@ static void ring_clear_env(ote_env* E, int e) {
   memset(E->ring + (size_t)e * E->cfg.n_pursuers * TE_RING_DEPTH * E->entry_words, 0,
          (size_t)E->cfg.n_pursuers * TE_RING_DEPTH * E->entry_words * sizeof(uint32_t));
 }
+/* SnapshotBuffer.get_snapshot(publisher, delta_step = age) at env-step `step` (lidar_buffer.py:79-103,159-166) in the
+ * canonical clock: the snapshot of step `step - age + 1`, or NULL when that wingman has none (not born yet, dead, or
+ * already slid out of the 10 slots) */
+static const uint32_t* ring_lookup(const ote_env* E, int e, int p, int step, int age) {
+  const int s = step - (age - 1);
+  if (age < 1 || age > TE_RING_DEPTH - 1 || s < 1) return NULL;
+  const uint32_t* ent = ring_entry(E, e, p, s);
+  return (int)ent[0] == s ? ent : NULL;
+}
+OTE_API int ote_ring_lookup(const ote_env* E, int e, int p, int age) {
+  if (!E->ring) return -1;
+  /* a disarmed wingman has no buffer at all: messageHub.terminate -> close_buffer -> remove_publisher
+   * (quadcopter.py:461-478, lidar_buffer.py:226-237,336-341); here it simply is no candidate any more */
+  if (!E->drones[(size_t)e * E->D + p].armed) return 0;
+  const uint32_t* ent = ring_lookup(E, e, p, E->envs[e].step, age);
+  return ent ? (int)ent[0] : 0;
+}
 static real cell_margin(real theta, real phi) {
   real ft = theta / OTE_PI * (real)TE_LIDAR_NTHETA, fp = (phi + OTE_PI) / ((real)2 * OTE_PI) * (real)TE_LIDAR_NPHI;
   real mt = fabs(ft - floor(ft + (real)0.5)) * OTE_PI / (real)TE_LIDAR_NTHETA;
@@ -904,10 +921,8 @@ static void stacked_observation(ote_env* E, int e, int step, uint32_t armed_now,
     stack_draws d;
     draw_stack(E, e, er->episode, step, armed_now & ((1u << c->n_pursuers) - 1u), &d);
     for (int i = 0; i < d.n; ++i) {
-      int s = step - (d.age[i] - 1);
-      if (s < 1) continue;
-      const uint32_t* nb = ring_entry(E, e, d.who[i], s);
-      if ((int)nb[0] != s) continue; /* get_snapshot -> None (lidar_buffer.py:152-154) */
+      const uint32_t* nb = ring_lookup(E, e, d.who[i], step, d.age[i]);
+      if (!nb) continue; /* get_snapshot -> None (lidar_buffer.py:152-154) */
       neighbor_sphere(E, e, nb, own, 0, d.age[i], stack[nv]); valid[nv++] = 1;
     }
     for (int i = nv; i < TE_STACK_SPHERES; ++i) sphere_ones(stack[i]);

@@ -41,6 +41,7 @@ def lib(precision: str = "f64") -> C.CDLL:
         L.ote_step.argtypes = [C.c_void_p] + [C.c_void_p] * 10 + [C.c_int]
         L.ote_margins.argtypes = [C.c_void_p, C.c_void_p]
         L.ote_stack_margins.argtypes = [C.c_void_p, C.c_void_p]
+        L.ote_ring_lookup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.ote_step_stacked.argtypes = [C.c_void_p] + [C.c_void_p] * 12 + [C.c_int]
         L.ote_observe_stacked.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.ote_stack_draws.argtypes = [C.POINTER(K.Config), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
@@ -145,6 +146,10 @@ class OracleEnv:
         out = np.empty(self.N, np.float64)
         self.L.ote_stack_margins(self.h, _p(out))
         return out
+
+    def ring_lookup(self, env: int, pursuer: int, age: int) -> int:
+        """Step stamp of the snapshot of `pursuer` that has `age` now (1 = freshest), 0 if there is none."""
+        return int(self.L.ote_ring_lookup(self.h, env, pursuer, age))
 
     def ring(self, words: Optional[np.ndarray] = None) -> np.ndarray:
         w = self.get_state() if words is None else words

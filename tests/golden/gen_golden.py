@@ -14,6 +14,7 @@ Outputs (inputs + expected outputs, all plain numeric arrays):
   kamikaze.npz       KamikazeNavigator (both variants) state + command traces
   geometry.npz       GeometryUtils cone / angle
   normalization.npz  normalize_inertial_data
+  snapshot_buffer.npz  lidar_buffer.SnapshotBuffer / LiDARBufferManager on a scripted publication history
   ref_level5_obs.npz decoded io_data0.h5 recorded observations (the only PyBullet-made numbers in the tree)
 """
 import importlib.util
@@ -244,6 +245,67 @@ def gen_normalization():
                         max_speed=10 * 1000 / 3600, dome_radius=20.0)
 
 
+def gen_snapshot_buffer():
+    """SnapshotBuffer / LiDARBufferManager (lidar_buffer.py:10-157,262-517) driven with a scripted publication history:
+    which snapshot `get_snapshot(publisher, delta)` returns at every step, its normalized_delta, who is a candidate
+    of `get_random_neighborhood`, and the (inclusive) range its ages are drawn from."""
+    from core.dataclasses.message_context import MessageContext
+    from core.entities.entity_type import EntityType
+    from core.notification_system.topics_enum import TopicsEnum
+
+    lb = by_path("ref_lidar_buffer", "core/entities/quadcopters/components/sensors/components/lidar_buffer.py")
+    T, P, I = 26, 6, 2
+    death = {1: 7, 3: 15, 4: 15, 5: 21}           # wingman -> step at which it is disarmed (publishes up to death - 1)
+    born = {p: 1 for p in range(P)}
+    mgr = lb.LiDARBufferManager(current_step=0, max_buffer_size=10)
+    ids = {p: 100 + p for p in range(P)}
+    inv_ids = {j: 200 + j for j in range(I)}
+    found = np.zeros((T + 1, P, 10), np.int32)     # payload (publication step) or 0
+    ndelta = np.zeros((T + 1, P, 10), np.float64)
+    cands = np.zeros((T + 1, P), np.uint8)
+    age_range = np.zeros((T + 1, 2), np.int32)
+    captured = {}
+
+    class Rand:  # stands in for the `random` module inside lidar_buffer.py: records instead of drawing
+        @staticmethod
+        def sample(population, k):
+            captured["candidates"] = list(population)
+            return list(population)[:k]
+
+        @staticmethod
+        def randint(a, b):
+            captured["range"] = (a, b)
+            return a
+
+    lb.random = Rand
+    for t in range(1, T + 1):
+        mgr.update_current_step(t)  # AGENT_STEP_BROADCAST (base_lidar.py:62-66)
+        for p in range(P):
+            if t == death.get(p, 10 ** 9):
+                mgr.close_buffer(ids[p], TopicsEnum.INERTIAL_DATA_BROADCAST)  # messageHub.terminate on disarm
+            if born[p] <= t < death.get(p, 10 ** 9):
+                ctx = MessageContext(publisher_id=ids[p], step=t - 1, entity_type=EntityType.LOYALWINGMAN)
+                mgr.buffer_message({"position": [float(t), 0.0, 0.0]}, ctx, TopicsEnum.INERTIAL_DATA_BROADCAST)
+                mgr.buffer_message({"features": [t]}, ctx, TopicsEnum.LIDAR_DATA_BROADCAST)
+        for j in range(I):
+            ctx = MessageContext(publisher_id=inv_ids[j], step=t - 1, entity_type=EntityType.LOITERINGMUNITION)
+            mgr.buffer_message({"position": [0.0, float(t), 0.0]}, ctx, TopicsEnum.INERTIAL_DATA_BROADCAST)
+        for p in range(P):
+            for d in range(1, 10):
+                snap = mgr._buffer.get_snapshot(ids[p], d)
+                if snap is not None and snap.lidar_features is not None:
+                    found[t, p, d] = snap.lidar_features[0]
+                    ndelta[t, p, d] = snap.normalized_delta
+        captured.clear()
+        mgr.get_random_neighborhood(n_neighbors=99)
+        for pid in captured.get("candidates", []):
+            cands[t, pid - 100] = 1
+        age_range[t] = captured.get("range", (0, 0))
+    np.savez_compressed(os.path.join(OUT, "snapshot_buffer.npz"), found=found, normalized_delta=ndelta, candidates=cands,
+                        age_range=age_range, death=np.array([[k, v] for k, v in death.items()], np.int32), T=T)
+    print("snapshot_buffer: lookups", int((found > 0).sum()), "of", found.size)
+
+
 def gen_h5_fixture():
     """Decode src/core/rl_framework/utils/output/collect_and_save/io_data0.h5 without h5py
     (HDF5 v1 B-tree chunk index, one uncompressed chunk per sample)."""
@@ -298,6 +360,7 @@ if __name__ == "__main__":
     gen_kamikaze(); print("kamikaze ok")
     gen_geometry(); print("geometry ok")
     gen_normalization(); print("normalization ok")
+    gen_snapshot_buffer()
     gen_h5_fixture()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

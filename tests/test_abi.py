@@ -25,7 +25,8 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.te_abi_version() == 1
+    from dronechase_amd import config as K
+    assert lib.te_abi_version() == K.TE_ABI_VERSION == 2
 
 
 def test_struct_layout_matches_c(lib):
@@ -55,6 +56,10 @@ def test_task_constants_are_the_references(lib):
     assert (e2.n_pursuers, e2.n_invaders, e2.n_rounds) == (1, 6, 6)  # calculate_rounds(1, 20) = 6
     e4 = default_config("exp04")
     assert e4.ally_policy == K.ALLY_FROZEN and e4.approach_bonus_gain == 10
+    l5 = default_config("level5")
+    # level5_task.py:76-98 ; calculate_max_rounds(6, 20, 12) = ceil((-23 + sqrt(23^2 + 8 * 121)) / 2) = 8
+    assert (l5.n_pursuers, l5.n_invaders, l5.n_rounds, l5.munition, l5.max_step, l5.stacked_obs) == (6, 12, 8, 20, 300, 1)
+    assert l5.ally_policy == K.ALLY_BT and l5.lidar_radius == 40 and e3.stacked_obs == 0
     s1 = default_config("stage01")
     assert (s1.n_pursuers, s1.n_invaders, s1.dome_radius, s1.lidar_radius, s1.munition, s1.max_step) == (2, 1, 10, 20, 0, 300)
     assert abs(s1.catch_distance - 0.4) < 1e-7
