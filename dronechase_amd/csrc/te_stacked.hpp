@@ -79,7 +79,10 @@ TE_DEV uint32_t* ring_entry_ptr(uint32_t* ring, int entry_words, int P, size_t e
 // the ring is written and read by different waves of one block: read around the (write-through, not coherent) L1
 TE_DEV uint32_t load_fresh(const uint32_t* p) { return __builtin_nontemporal_load(p); }
 
-// (2) FusedLIDAR.bootstrap / randomize_stack draws; must match oracle/te_oracle.c:draw_stack word for word
+// (2) FusedLIDAR.bootstrap / randomize_stack draws (fused_lidar.py:73-81,246-262; lidar_buffer.py:110-157): n ~ U{1..4};
+// n distinct armed wingmen (the agent included) without replacement; an age ~ U{1..9} each; a uniform permutation of
+// the six (sphere, valid) pairs.  16 Philox words keyed (STACK, slot 0, sub 0..3, episode, step); an integer in
+// [0, k) is (word * k) >> 32.  The test checker restates exactly this sequence.
 TE_DEV void draw_stack(const te_config& c, int env, uint32_t episode, uint32_t step, uint32_t armed_pursuers, int P, int& n,
                        uint32_t& who, uint32_t& age, uint32_t& perm) {
   uint32_t w[16];

@@ -28,23 +28,30 @@ class _SingleEnv:
         self.cfg = make_config(self.TASK, 1, self.dome_radius, rl_frequency, seed, auto_reset=0, **overrides)
         self._b = BatchedEnv(self.cfg, device)
         self.action_space = spaces.action_space()
-        self.observation_space = spaces.observation_space()
+        self.stacked = bool(self.cfg.stacked_obs)
+        self.observation_space = spaces.stacked_observation_space() if self.stacked else spaces.observation_space()
 
-    def _obs(self, lidar, inertial, last_action):
+    def _obs(self, *t):
+        if self.stacked:
+            stacked, mask, inertial, last_action = t
+            return {"stacked_spheres": stacked[0].cpu().numpy(), "validity_mask": mask[0].cpu().numpy().astype(bool),
+                    "inertial_data": inertial[0].cpu().numpy(), "last_action": last_action[0].cpu().numpy()}
+        lidar, inertial, last_action = t
         return {"lidar": lidar[0].cpu().numpy(), "inertial_data": inertial[0].cpu().numpy(),
                 "last_action": last_action[0].cpu().numpy()}
 
     def reset(self, seed=0, options=None):
         """`seed` is accepted and ignored, as in the reference (exp03_vFinal_environment.py:128-146)."""
-        return self._obs(*self._b.reset()), {}
+        self._b.reset()
+        return self._obs(*(self._b.observe_stacked() if self.stacked else self._b.observe())), {}
 
     def step(self, rl_action: np.ndarray):
         import torch
 
         a = torch.as_tensor(np.asarray(rl_action, np.float32).reshape(1, 4), device=self._b.device)
-        lidar, inertial, last_action, reward, done, info = self._b.step(a, terminal=False)
+        *obs, reward, done, info = (self._b.step_stacked if self.stacked else self._b.step)(a, terminal=False)
         inf = dict(zip(INFO_KEYS, (int(v) for v in info[0].cpu().numpy())))
-        return self._obs(lidar, inertial, last_action), float(reward[0].item()), bool(done[0].item()), False, inf
+        return self._obs(*obs), float(reward[0].item()), bool(done[0].item()), False, inf
 
     def close(self):
         self._b.close()
@@ -72,5 +79,9 @@ class PyflytL3EnviromentV2(_SingleEnv):  # level3/pyflyt_level3_environment_v2.p
     DEFAULT_DOME = 8.0
 
 
+class Level5Environment(_SingleEnv):  # threatsense/level5/level5_envrionment.py:32 (student observation)
+    TASK = "level5"
+
+
 ENV_TASKS = {cls: cls.TASK for cls in (Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment,
-                                       PyflytL2EnviromentModifiedV2, PyflytL3EnviromentV2)}
+                                       PyflytL2EnviromentModifiedV2, PyflytL3EnviromentV2, Level5Environment)}

@@ -71,3 +71,15 @@ def observation_space(lidar_shape=(3, 13, 26)) -> "Dict":
         "last_action": Box(np.array([-1, -1, -1, 0], np.float32), np.array([1, 1, 1, 1], np.float32), shape=(4,),
                            dtype=np.float32),
     })
+
+
+def stacked_observation_space(n_spheres=6, sphere_shape=(3, 13, 26)) -> "Dict":
+    """level5 student observation: Dict{stacked_spheres [6,C,13,26] in [0,1]; validity_mask [6] in {0,1};
+    inertial_data [15]; last_action [4]} (threatsense/level5/level5_envrionment.py:312-351,380-440)."""
+    return Dict({
+        "stacked_spheres": Box(0, 1, shape=(n_spheres, *sphere_shape), dtype=np.float32),
+        "validity_mask": Box(0, 1, shape=(n_spheres,), dtype=np.uint8),
+        "inertial_data": Box(-np.ones(15, np.float32), np.ones(15, np.float32), shape=(15,), dtype=np.float32),
+        "last_action": Box(np.array([-1, -1, -1, 0], np.float32), np.array([1, 1, 1, 1], np.float32), shape=(4,),
+                           dtype=np.float32),
+    })

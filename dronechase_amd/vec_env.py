@@ -81,7 +81,8 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
             backend = BatchedEnv(self.cfg, device)
         self.backend = backend
         self.num_envs = int(num_envs)
-        self.observation_space = spaces.observation_space()
+        self.stacked = bool(self.cfg.stacked_obs)  # level5: stacked_spheres + validity_mask instead of lidar
+        self.observation_space = spaces.stacked_observation_space() if self.stacked else spaces.observation_space()
         self.action_space = spaces.action_space()
         self.render_mode = None
         self.reset_infos: List[Dict[str, Any]] = [{} for _ in range(self.num_envs)]
@@ -94,7 +95,12 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
     def _to_out(self, t):
         return t if self.output == "torch" else t.detach().cpu().numpy()
 
-    def _obs(self, lidar, inertial, last_action):
+    def _obs(self, *t):
+        if self.stacked:
+            stacked, mask, inertial, last_action = t
+            return {"stacked_spheres": self._to_out(stacked), "validity_mask": self._to_out(mask.bool()),
+                    "inertial_data": self._to_out(inertial), "last_action": self._to_out(last_action)}
+        lidar, inertial, last_action = t
         return {"lidar": self._to_out(lidar), "inertial_data": self._to_out(inertial), "last_action": self._to_out(last_action)}
 
     def _as_device_actions(self, actions):
@@ -108,11 +114,13 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
 
     # ------------------------------------------------------------------ VecEnv API
     def reset(self):
-        lidar, inertial, last_action = self.backend.reset()
+        obs = self.backend.reset()
+        if self.stacked:
+            obs = self.backend.observe_stacked()
         self.reset_infos = [{} for _ in range(self.num_envs)]
         self._seeds = [None] * self.num_envs
         self._options = [{} for _ in range(self.num_envs)]
-        return self._obs(lidar, inertial, last_action)
+        return self._obs(*obs)
 
     def step_async(self, actions) -> None:
         self._actions = self._as_device_actions(actions)
@@ -121,22 +129,23 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
         if self._actions is None:
             raise RuntimeError("step_wait() without step_async()")
         b = self.backend
-        lidar, inertial, last_action, reward, done, info = b.step(self._actions, terminal=True)
+        *obs_t, reward, done, info = (b.step_stacked if self.stacked else b.step)(self._actions, terminal=True)
         self._actions = None
-        obs = self._obs(lidar, inertial, last_action)
+        obs = self._obs(*obs_t)
         done_np = done.detach().cpu().numpy().astype(bool)
         info_np = info.detach().cpu().numpy()
         terminal = None
         if done_np.any():
+            tbuf = ({"stacked_spheres": b.t_stacked, "validity_mask": b.t_mask.bool()} if self.stacked else {"lidar": b.t_lidar})
+            tbuf.update({"inertial_data": b.t_inertial, "last_action": b.t_last_action})
             if self.output == "torch":
-                terminal = {"lidar": b.t_lidar, "inertial_data": b.t_inertial, "last_action": b.t_last_action}
+                terminal = tbuf
             else:  # copy only the rows that are valid
                 idx = np.flatnonzero(done_np)
                 import torch
 
                 ti = torch.from_numpy(idx).to(b.device)
-                rows = {"lidar": b.t_lidar[ti].cpu().numpy(), "inertial_data": b.t_inertial[ti].cpu().numpy(),
-                        "last_action": b.t_last_action[ti].cpu().numpy()}
+                rows = {k: v[ti].cpu().numpy() for k, v in tbuf.items()}
                 terminal = {k: _ScatterRows(idx, v, self.num_envs) for k, v in rows.items()}
         infos = LazyInfos(info_np, done_np, terminal)
         if self.infos_mode == "dicts":

@@ -152,3 +152,38 @@ def test_stacked_full_size_properties_and_api_errors():
     with pytest.raises(_lib.TEError, match="stacked_obs"):
         plain.L.te_step_stacked  # attribute exists
         _lib.check(plain.L.te_observe_stacked(plain._h, None, None, None, None, None), "te_observe_stacked")
+
+
+def test_level5_vecenv_and_single_env_surface():
+    """The reference's level5 student observation dict (level5_envrionment.py:312-351,359-362) through the SB3 VecEnv
+    mirror and the single-env class."""
+    _gpu()
+    from dronechase_amd.envs import Level5Environment
+    from dronechase_amd.pipeline import ReinforcementLearningPipeline
+    n = 96
+    v = ReinforcementLearningPipeline.create_vectorized_environment(Level5Environment, {"dome_radius": 20, "rl_frequency": 15},
+                                                                    n_envs=n, monitor=False, max_step=5)
+    assert v.observation_space["stacked_spheres"].shape == (6, 3, 13, 26) and v.observation_space["validity_mask"].shape == (6,)
+    obs = v.reset()
+    assert set(obs) == {"stacked_spheres", "validity_mask", "inertial_data", "last_action"}
+    assert obs["stacked_spheres"].shape == (n, 6, 3, 13, 26) and obs["validity_mask"].dtype == bool and not obs["validity_mask"].any()
+    saw_terminal = False
+    for t in range(8):
+        a = np.tile(np.array([[0.3, -0.2, 0.1, 0.5]], np.float32), (n, 1))
+        obs, rew, dones, infos = v.step(a)
+        assert obs["validity_mask"].shape == (n, 6) and rew.shape == (n,)
+        for i in np.flatnonzero(dones):
+            t_obs = infos[i]["terminal_observation"]
+            assert t_obs["stacked_spheres"].shape == (6, 3, 13, 26) and t_obs["validity_mask"].sum() >= 1
+            assert not obs["validity_mask"][i].any()      # reset observation of the auto-reset env
+            saw_terminal = True
+        live = ~dones
+        assert (obs["validity_mask"][live].sum(1) >= 1).all()
+    assert saw_terminal
+    v.close()
+    e = Level5Environment(dome_radius=20, rl_frequency=15)
+    o, info = e.reset()
+    assert o["stacked_spheres"].shape == (6, 3, 13, 26) and not o["validity_mask"].any()
+    o, r, term, trunc, info = e.step(np.array([0, 0, 1, 0.5], np.float32))
+    assert o["validity_mask"].sum() >= 1 and set(info) >= {"agent_kills", "allies_kills", "deads", "current_wave"} and trunc is False
+    e.close()
