@@ -44,19 +44,23 @@ struct StackRows {
   TE_DEV int step() const { return armed() + 1; }
   TE_DEV int episode() const { return armed() + 2; }
   TE_DEV int done() const { return armed() + 3; }
+  // phase (1) uses feat + work, phase (3) re-uses the same rows for the four neighbour lists (157 >= 136 rows at D = 18):
+  // the block stays below 80 KB of LDS, i.e. two blocks per CU
   TE_DEV int feat() const { return armed() + 4; }             // 4*D : r_hat, theta, phi, cell of drone j seen from wingman p
-  TE_DEV int own_n() const { return feat() + 4 * D; }         // 1   : kept features of the agent's own sphere
+  TE_DEV int work() const { return feat() + 4 * D; }          // 5*F : closer-wins working list (cell, r_hat, theta, phi, meta)
+  TE_DEV int nb_k() const { return feat(); }                  // 4 * 2*F (aliases feat + work): cell | type << 16, r_hat
+  TE_DEV int own_n() const { return work() + 5 * F(); }       // 1   : kept features of the agent's own sphere
   TE_DEV int own_k() const { return own_n() + 1; }            // 2*F : cell | type << 16, r_hat
   TE_DEV int dn() const { return own_k() + 2 * F(); }         // 1   : neighbours drawn
   TE_DEV int dwho() const { return dn() + 1; }                // 1   : 4 x 8 bits
   TE_DEV int dage() const { return dn() + 2; }                // 1   : 4 x 8 bits
   TE_DEV int dperm() const { return dn() + 3; }               // 1   : 6 x 4 bits, out[i] = stack[perm[i]]
   TE_DEV int nb_n() const { return dn() + 4; }                // 4   : kept features of neighbour k, or 0xFFFFFFFF = no sphere
-  TE_DEV int nb_k() const { return nb_n() + 4; }              // 4 * 2*F
-  TE_DEV int opos() const { return nb_k() + 8 * F(); }        // 5   : output position of own / neighbour k (or 0xFF)
+  TE_DEV int opos() const { return nb_n() + 4; }              // 5   : output position of own / neighbour k (or 0xFF)
   TE_DEV int total() const { return opos() + 5; }
 };
-__host__ __device__ inline int stack_lds_rows(int D, int P) { return 3 * D + 4 * P + 4 + 4 * D + 1 + 2 * (D - 1) + 4 + 4 + 8 * (D - 1) + 5; }
+__host__ __device__ inline int stack_lds_rows(int D, int P) { return 3 * D + 4 * P + 4 + 4 * D + 5 * (D - 1) + 1 + 2 * (D - 1) + 4 + 4 + 5; }
+static_assert(4 * 32 + 5 * 31 >= 8 * 31, "the neighbour lists must fit in feat + work");
 
 TE_DEV V3 rotate_by(Q4 q, V3 v) { return mul(rotation(q), v); }  // pybullet rotateVector
 TE_DEV Q4 inverse_of(Q4 q) {  // LidarMath._invert_quaternion (lidar_math.py:40-51)
@@ -169,40 +173,54 @@ __global__ __launch_bounds__(256) void stacked_kernel(StackParams p, StackOut o)
         row(r.feat() + 2 * D + j, l) = __float_as_uint(ph); row(r.feat() + 3 * D + j, l) = (uint32_t)cell;
       }
       __syncthreads();
-      if (tid < kEPB && tid < nvalid && ((row(r.armed(), tid) >> pp) & 1u)) {  // closer wins per cell, in slot order (lidar_math.py:262-311)
-        const int l = tid, step = (int)row(r.step(), l);
-        // working list in the (still unused) neighbour rows: 5 words per kept feature = cell, r_hat, theta, phi, meta
-        const int wk = r.nb_k();
-        int n = 0;
-        for (int j = 0; j < D; ++j) {
-          const uint32_t cell = row(r.feat() + 3 * D + j, l);
-          if (cell == 0xFFFFFFFFu) continue;
-          const float rhat = rowf(r.feat() + 0 * D + j, l);
-          int at = -1;
-          for (int k = 0; k < n; ++k) if (row(wk + 5 * k, l) == cell) at = k;
-          if (at < 0) { if (!(rhat < 1.0f)) continue; at = n++; }  // an empty cell holds 1.0: strict '<'
-          else if (!(rhat < rowf(wk + 5 * at + 1, l))) continue;
-          row(wk + 5 * at, l) = cell; row(wk + 5 * at + 1, l) = __float_as_uint(rhat);
-          row(wk + 5 * at + 2, l) = row(r.feat() + 1 * D + j, l); row(wk + 5 * at + 3, l) = row(r.feat() + 2 * D + j, l);
-          row(wk + 5 * at + 4, l) = (uint32_t)(j < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) | ((uint32_t)j << 8);
-        }
-        uint32_t* ent = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), pp, step);
-        const V3 me = pos_of(pp, l); const Q4 q = quat_of(pp, l);
-        ent[0] = (uint32_t)step; ent[1] = (uint32_t)n;
-        ent[2] = __float_as_uint(me.x); ent[3] = __float_as_uint(me.y); ent[4] = __float_as_uint(me.z);
-        ent[5] = __float_as_uint(q.x); ent[6] = __float_as_uint(q.y); ent[7] = __float_as_uint(q.z); ent[8] = __float_as_uint(q.w);
-        ent[9] = ent[10] = ent[11] = 0u;
-        for (int k = 0; k < D - 1; ++k) {
-          uint4 f = make_uint4(0u, 0u, 0u, 0u);
-          if (k < n) {
-            f = make_uint4(row(wk + 5 * k + 1, l), row(wk + 5 * k + 2, l), row(wk + 5 * k + 3, l), row(wk + 5 * k + 4, l));
-            if (pp == 0) {  // the agent keeps (cell, type, r_hat) of its own sphere for the patch phase
-              row(r.own_k() + 2 * k, l) = row(wk + 5 * k, l) | ((f.w & 0xFFu) << 16); row(r.own_k() + 2 * k + 1, l) = f.x;
-            }
+      // closer wins per cell (lidar_math.py:262-311), evaluated per (env, drone j) item instead of walking a list:
+      //   j is a CLAIMANT of its cell if it is in view with r_hat < 1 (an empty cell holds 1.0, strict '<');
+      //   the kept feature of a cell is its closest claimant (ties: lowest slot, as a later equal range does not replace);
+      //   the cells appear in the entry in the order of their first claimant (the reference's dict insertion order).
+      // Step (i): leader flag (first claimant of its cell) and the cell's winner; step (ii): position = leaders before me.
+      const int lead = r.work(), win = r.work() + D;
+      for (int it = tid; it < kEPB * D; it += blockDim.x) {
+        const int l = it & (kEPB - 1), j = it / kEPB;
+        const uint32_t cell = row(r.feat() + 3 * D + j, l);
+        uint32_t is_lead = 0u, w = (uint32_t)j;
+        if (cell != 0xFFFFFFFFu && rowf(r.feat() + j, l) < 1.0f) {
+          is_lead = 1u;
+          float best = rowf(r.feat() + j, l);
+          for (int k = 0; k < D; ++k) {
+            if (k == j || row(r.feat() + 3 * D + k, l) != cell) continue;
+            const float rk = rowf(r.feat() + k, l);
+            if (!(rk < 1.0f)) continue;
+            if (k < j) is_lead = 0u;
+            if (rk < best || (rk == best && k < (int)w)) { best = rk; w = (uint32_t)k; }
           }
-          *reinterpret_cast<uint4*>(ent + TE_RING_HEADER_WORDS + 4 * k) = f;
         }
-        if (pp == 0) row(r.own_n(), l) = (uint32_t)n;
+        row(lead + j, l) = is_lead; row(win + j, l) = w;
+      }
+      __syncthreads();
+      for (int it = tid; it < kEPB * D; it += blockDim.x) {
+        const int l = it & (kEPB - 1), j = it / kEPB;
+        if (l >= nvalid || !((row(r.armed(), l) >> pp) & 1u)) continue;
+        const int step = (int)row(r.step(), l);
+        uint32_t* ent = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), pp, step);
+        if (j == pp) {  // this item has no feature of its own: it writes the header
+          uint32_t n = 0u;
+          for (int k = 0; k < D; ++k) n += row(lead + k, l);
+          const V3 me = pos_of(pp, l); const Q4 q = quat_of(pp, l);
+          *reinterpret_cast<uint4*>(ent) = make_uint4((uint32_t)step, n, __float_as_uint(me.x), __float_as_uint(me.y));
+          *reinterpret_cast<uint4*>(ent + 4) = make_uint4(__float_as_uint(me.z), __float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z));
+          *reinterpret_cast<uint4*>(ent + 8) = make_uint4(__float_as_uint(q.w), 0u, 0u, 0u);
+          if (pp == 0) row(r.own_n(), l) = n;
+        } else if (row(lead + j, l)) {
+          uint32_t at = 0u;
+          for (int k = 0; k < j; ++k) at += row(lead + k, l);
+          const int w = (int)row(win + j, l);
+          const uint32_t meta = (uint32_t)(w < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) | ((uint32_t)w << 8);
+          const uint4 f = make_uint4(row(r.feat() + 0 * D + w, l), row(r.feat() + 1 * D + w, l), row(r.feat() + 2 * D + w, l), meta);
+          *reinterpret_cast<uint4*>(ent + TE_RING_HEADER_WORDS + 4 * at) = f;   // slots >= n keep stale words: never read
+          if (pp == 0) {  // the agent keeps (cell, type, r_hat) of its own sphere for the patch phase
+            row(r.own_k() + 2 * at, l) = row(r.feat() + 3 * D + j, l) | ((meta & 0xFFu) << 16); row(r.own_k() + 2 * at + 1, l) = f.x;
+          }
+        }
       }
       __syncthreads();
     }
