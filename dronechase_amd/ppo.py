@@ -1,0 +1,198 @@
+"""On-device PPO for the batched environments (BASELINE.json config 5).
+
+The reference trains SB3 PPO (`MultiInputPolicy` + `LidarInertialActionExtractor`,
+src/core/rl_framework/agents/policies/ppo_policies.py:234-341; apps/threatengage_runner/stage03/...) against
+`SubprocVecEnv`, i.e. every observation crosses process pipes and PCIe.  stable-baselines3 is not installed here, and
+with 65 536 environments per GPU the rollout buffer is the thing to keep on the device: this module is a plain-PyTorch
+PPO whose rollout storage, advantage estimation and minibatches never leave HBM (a 128-step rollout of 65 536 stage03
+envs is 34 GB of observations — 288 GB per MI355X is what makes that layout possible).  PyTorch-ROCm is used for
+autograd and the dense layers (rocBLAS/MIOpen): the environment side stays the HIP kernels of libthreatengage.so.
+
+  * topology = the reference's extractor: LIDAR conv(k4,s4,32) -> conv(k2,s2,64) -> flatten; inertial and
+    last_action 3 x Linear(128); concat -> Linear(256); then SB3's default pi / vf heads (2 x 64, tanh) and a
+    state-independent log-std (stable_baselines3 ActorCriticPolicy defaults);
+  * losses / GAE = the PPO of Schulman et al. 2017 with SB3's defaults (clip 0.2, gae_lambda 0.95, gamma 0.99,
+    vf_coef 0.5, ent_coef 0, max_grad_norm 0.5, advantage normalisation per minibatch, 10 epochs);
+  * multi-GPU: one process per GPU, each with its own env shard; gradients are averaged with
+    torch.distributed all_reduce (RCCL) — the only collective of the whole system, once per minibatch.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+
+class LidarInertialActionPolicy(nn.Module):
+    """Actor-critic over {"lidar" [B,C,13,26], "inertial_data" [B,15], "last_action" [B,4]}."""
+
+    def __init__(self, lidar_shape=(3, 13, 26), inertial_dim: int = 15, action_dim: int = 4, features_dim: int = 256):
+        super().__init__()
+        c = lidar_shape[0]
+        self.lidar = nn.Sequential(nn.Conv2d(c, 32, kernel_size=4, stride=4), nn.ReLU(),
+                                   nn.Conv2d(32, 64, kernel_size=2, stride=2), nn.ReLU(), nn.Flatten())
+        with torch.no_grad():
+            n_lidar = self.lidar(torch.zeros(1, *lidar_shape)).shape[1]
+
+        def mlp(n_in):
+            return nn.Sequential(nn.Linear(n_in, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU())
+
+        self.inertial, self.action = mlp(inertial_dim), mlp(action_dim)
+        self.final = nn.Sequential(nn.Linear(n_lidar + 256, features_dim), nn.ReLU())
+        self.pi = nn.Sequential(nn.Linear(features_dim, 64), nn.Tanh(), nn.Linear(64, 64), nn.Tanh())
+        self.vf = nn.Sequential(nn.Linear(features_dim, 64), nn.Tanh(), nn.Linear(64, 64), nn.Tanh())
+        self.mu = nn.Linear(64, action_dim)
+        self.value = nn.Linear(64, 1)
+        self.log_std = nn.Parameter(torch.zeros(action_dim))
+
+    def features(self, obs: Dict[str, torch.Tensor]) -> torch.Tensor:
+        z = torch.cat((self.lidar(obs["lidar"]), self.inertial(obs["inertial_data"]), self.action(obs["last_action"])), dim=1)
+        return self.final(z)
+
+    def forward(self, obs):
+        f = self.features(obs)
+        return self.mu(self.pi(f)), self.value(self.vf(f)).squeeze(-1)
+
+    def dist(self, obs):
+        mu, v = self(obs)
+        return torch.distributions.Normal(mu, self.log_std.exp().expand_as(mu)), v
+
+
+@dataclass
+class PPOConfig:
+    n_steps: int = 128
+    batch_size: int = 2048
+    n_epochs: int = 10
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_range: float = 0.2
+    vf_coef: float = 0.5
+    ent_coef: float = 0.0
+    max_grad_norm: float = 0.5
+    learning_rate: float = 3e-4
+    reward_scale: float = 1e-3   # rewards reach +-1000 (exp03_vFinal_task.py:423-515); SB3 users wrap VecNormalize
+
+
+class RolloutBuffer:
+    """[n_steps, N, ...] tensors on the environment's device."""
+
+    def __init__(self, n_steps: int, n_envs: int, obs_shapes: Dict[str, tuple], device):
+        f = dict(dtype=torch.float32, device=device)
+        self.obs = {k: torch.empty((n_steps, n_envs, *s), **f) for k, s in obs_shapes.items()}
+        self.actions = torch.empty((n_steps, n_envs, 4), **f)
+        self.logp = torch.empty((n_steps, n_envs), **f)
+        self.values = torch.empty((n_steps, n_envs), **f)
+        self.rewards = torch.empty((n_steps, n_envs), **f)
+        self.dones = torch.empty((n_steps, n_envs), **f)          # done AFTER this step
+        self.adv = torch.empty((n_steps, n_envs), **f)
+        self.ret = torch.empty((n_steps, n_envs), **f)
+
+    def bytes(self) -> int:
+        ts = list(self.obs.values()) + [self.actions, self.logp, self.values, self.rewards, self.dones, self.adv, self.ret]
+        return sum(t.numel() * t.element_size() for t in ts)
+
+    @torch.no_grad()
+    def finish(self, last_value: torch.Tensor, gamma: float, lam: float) -> None:
+        """GAE(lambda).  An env that auto-reset at step t starts a new episode at t+1: no bootstrap across it
+        (terminations only: the reference never truncates, exp03_vFinal_environment.py:166)."""
+        gae = torch.zeros_like(last_value)
+        nxt = last_value
+        for t in reversed(range(self.rewards.shape[0])):
+            nonterminal = 1.0 - self.dones[t]
+            delta = self.rewards[t] + gamma * nxt * nonterminal - self.values[t]
+            gae = delta + gamma * lam * nonterminal * gae
+            self.adv[t] = gae
+            nxt = self.values[t]
+        self.ret.copy_(self.adv + self.values)
+
+
+class PPO:
+    """`env` is a dronechase_amd.batched_env.BatchedEnv (classic own-sphere observation)."""
+
+    def __init__(self, env, cfg: Optional[PPOConfig] = None, policy: Optional[nn.Module] = None, seed: int = 0):
+        self.env, self.cfg = env, cfg or PPOConfig()
+        self.device = env.device
+        torch.manual_seed(seed)
+        self.policy = (policy or LidarInertialActionPolicy()).to(self.device)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5)
+        shapes = {"lidar": tuple(env.lidar.shape[1:]), "inertial_data": (env.inertial.shape[1],), "last_action": (4,)}
+        self.buf = RolloutBuffer(self.cfg.n_steps, env.N, shapes, self.device)
+        self.low = torch.tensor([-1.0, -1.0, -1.0, 0.0], device=self.device)
+        self.high = torch.ones(4, device=self.device)
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if self.distributed:  # same initial weights on every rank
+            for p in self.policy.parameters():
+                torch.distributed.broadcast(p.data, src=0)
+        lidar, inertial, last_action = env.reset()
+        self._obs = {"lidar": lidar, "inertial_data": inertial, "last_action": last_action}
+        self.num_timesteps = 0
+
+    def _current_obs(self):
+        return self._obs
+
+    @torch.no_grad()
+    def collect(self) -> Dict[str, float]:
+        b, c = self.buf, self.cfg
+        ep_rew, ep_n = 0.0, 0
+        for t in range(c.n_steps):
+            obs = self._current_obs()
+            for k in b.obs:
+                b.obs[k][t].copy_(obs[k])
+            dist, v = self.policy.dist(obs)
+            a = dist.sample()
+            b.actions[t], b.logp[t], b.values[t] = a, dist.log_prob(a).sum(-1), v
+            lidar, inertial, last_action, reward, done, _info = self.env.step(torch.max(torch.min(a, self.high), self.low).contiguous(), terminal=False)
+            b.rewards[t] = reward * c.reward_scale
+            b.dones[t] = done.float()
+            self._obs = {"lidar": lidar, "inertial_data": inertial, "last_action": last_action}
+            ep_rew += float(reward.mean()); ep_n += int(done.sum())
+        _, last_v = self.policy(self._current_obs())
+        b.finish(last_v, c.gamma, c.gae_lambda)
+        self.num_timesteps += c.n_steps * self.env.N
+        return {"mean_step_reward": ep_rew / c.n_steps, "episodes_finished": ep_n}
+
+    def update(self) -> Dict[str, float]:
+        b, c = self.buf, self.cfg
+        T, N = b.rewards.shape
+        flat = lambda x: x.reshape(T * N, *x.shape[2:])
+        obs = {k: flat(v) for k, v in b.obs.items()}
+        actions, old_logp, adv, ret = flat(b.actions), flat(b.logp), flat(b.adv), flat(b.ret)
+        stats = {"pg_loss": 0.0, "v_loss": 0.0, "entropy": 0.0, "clip_frac": 0.0, "n": 0}
+        for _ in range(c.n_epochs):
+            perm = torch.randperm(T * N, device=self.device)
+            for s in range(0, T * N, c.batch_size):
+                idx = perm[s:s + c.batch_size]
+                dist, v = self.policy.dist({k: o[idx] for k, o in obs.items()})
+                logp = dist.log_prob(actions[idx]).sum(-1)
+                a = adv[idx]
+                a = (a - a.mean()) / (a.std() + 1e-8)
+                ratio = (logp - old_logp[idx]).exp()
+                pg = -torch.min(a * ratio, a * ratio.clamp(1 - c.clip_range, 1 + c.clip_range)).mean()
+                vl = torch.nn.functional.mse_loss(v, ret[idx])
+                ent = dist.entropy().sum(-1).mean()
+                loss = pg + c.vf_coef * vl - c.ent_coef * ent
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                if self.distributed:
+                    ws = torch.distributed.get_world_size()
+                    for p in self.policy.parameters():
+                        if p.grad is not None:
+                            torch.distributed.all_reduce(p.grad)
+                            p.grad.div_(ws)
+                nn.utils.clip_grad_norm_(self.policy.parameters(), c.max_grad_norm)
+                self.opt.step()
+                with torch.no_grad():
+                    stats["pg_loss"] += float(pg); stats["v_loss"] += float(vl); stats["entropy"] += float(ent)
+                    stats["clip_frac"] += float(((ratio - 1).abs() > c.clip_range).float().mean()); stats["n"] += 1
+        n = max(stats.pop("n"), 1)
+        return {k: v / n for k, v in stats.items()}
+
+    def learn(self, total_timesteps: int, log=None):
+        while self.num_timesteps < total_timesteps:
+            r = self.collect()
+            u = self.update()
+            if log:
+                log({**r, **u, "timesteps": self.num_timesteps})
+        return self
