@@ -302,6 +302,10 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
   // (FillJob): only the hit cells are patched here.
   TE_STAMP(p, 500, 0);
   if (threadIdx.x < kEPB) sm[r.task() * kEPB + threadIdx.x] = 0u;
+  // the logic lane's action: requested now, consumed two barriers later (a load issued inside the logic phase was a
+  // 2 us stall at its very top)
+  float4 my_action = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (threadIdx.x < kEPB && (int)threadIdx.x < nvalid) my_action = reinterpret_cast<const float4*>(actions)[env0 + threadIdx.x];
   stage_block(p, sm, r, env0);
   __syncthreads();
   TE_STAMP(p, 500, 1);
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
   if (threadIdx.x < kEPB && (int)threadIdx.x < nvalid) {
     const int lane = threadIdx.x;
     SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + lane, r.P}, sm, lane, r, p.D, r.P, env0 + lane, true};
-    const float4 a = reinterpret_cast<const float4*>(actions)[env0 + lane];
+    const float4 a = my_action;
     if (FAMILY == FAM_STAGE01) stage01_logic(p.cfg, v, a, o);
     else if (FAMILY == FAM_STAGE02) stage02_logic(p.cfg, v, a, o);
     else level4_logic(p.cfg, v, a, o);

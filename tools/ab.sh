@@ -1,6 +1,5 @@
-cd /tmp && export TMPDIR=/tmp
-for lim in 1 2 3 0; do
-  rm -rf /tmp/p5
-  TE_STACK_LIMIT=$lim rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5 -o l5 -- python3 $GRAFT_REPO_ROOT/tools/level5_bench.py 65536 40 > /dev/null 2>&1
-  echo "limit $lim: $(find /tmp/p5 -name '*kernel_stats.csv' -exec grep stacked_kernel {} \; | cut -d, -f4)"
-done
+# A/B of two prebuilt libraries (ab/libA.so = HEAD, ab/libB.so = working tree) inside one gpurun call
+for r in 1 2; do for v in A B; do
+  cp ab/lib$v.so dronechase_amd/libthreatengage.so
+  echo "$v: $(python bench.py --steps 200 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["value"]/1e6,1), round(d["roofline_env_step"]["substeps_kernel_ms"]*1e3,1), round(d["roofline_env_step"]["engage_observe_kernel_ms"]*1e3,1))')"
+done; done
