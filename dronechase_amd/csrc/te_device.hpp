@@ -39,6 +39,10 @@ struct Params {
   uint32_t* dstate;
   uint32_t* estate;
   int N, Npad, D;
+  // bit s of slot_mask[chunk] = some env of that chunk of 64 has drone s armed: written by the engage/observe launch
+  // (and by reset / set_state), read by the sub-step launch with a SCALAR load, so that a wave with nothing to fly
+  // retires without a single vector memory operation
+  uint32_t* slot_mask;  // [Npad / 64]
   // level5 (cfg.stacked_obs): observation-time snapshot planes (te_stacked.hpp SnapRows) and the snapshot ring; else null
   uint32_t* snap;
   uint32_t* ring;

@@ -49,8 +49,7 @@ namespace te {
 #else
 #define TE_K1_ATTR
 #endif
-// Background job of one launch.  The first D * Npad quads are written by the drone waves (one float4 per lane, see
-// the note on register allocation below), the rest by the fill waves, grid-stride.
+// Background job of one launch: the fill waves cover the whole buffer, grid-stride.
 struct FillJob { float* lidar; uint32_t total_quads; uint32_t n_fill_waves; };
 
 // what kamikaze_update() reads of the other drones, through the wave's buffer resource
@@ -72,8 +71,8 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
     if (wave < (int)fill.n_fill_waves) {  // ---- fill wave
       // grid-stride: at any moment the fill waves write one contiguous n_fill_waves KB window, which the address
       // interleave spreads over every HBM channel
-      const uint32_t first = (uint32_t)(D * nchunks) * 64u, stride = fill.n_fill_waves * 64u;
-      for (uint32_t q = first + (uint32_t)wave * 64u + (uint32_t)lane; q < fill.total_quads; q += stride) fill_dst[q] = ones;
+      const uint32_t stride = fill.n_fill_waves * 64u;
+      for (uint32_t q = (uint32_t)wave * 64u + (uint32_t)lane; q < fill.total_quads; q += stride) fill_dst[q] = ones;
       return;
     }
     wave -= (int)fill.n_fill_waves;
@@ -81,6 +80,10 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   const int slot = wave / nchunks;
   const int chunk = wave - slot * nchunks;
   if (slot >= D) return;
+  // Is any drone of this (slot, chunk) armed?  One wave-uniform SCALAR load: the ~8 000 idle waves of a launch used to
+  // wait for a vector flag load (and issue a background store) behind the fill waves' stores: +15 us per launch.
+  const uint32_t chunk_mask = __builtin_amdgcn_readfirstlane(((const uint32_t* __restrict__)p.slot_mask)[chunk]);
+  if (!((chunk_mask >> slot) & 1u)) return;
   const int env = chunk * 64 + lane;  // planes are padded to Npad: lanes beyond N still read in bounds
   const SlotLane P(p.dstate, p.estate, (uint32_t)D, (uint32_t)p.Npad, (uint32_t)slot, (uint32_t)env,
                    (uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)D * (uint32_t)p.Npad, (uint32_t)TE_ENV_WORDS * (uint32_t)p.Npad);
@@ -126,10 +129,6 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
     // stage01 counts step_calls BEFORE the sim loop (pyflyt_level2_environment_modified_v2.py:128)
     step_index = (uint32_t)P.lei(TE_E_STEP) + (FAMILY == FAM_STAGE01 ? 1u : 0u);
   }
-  // ONE background store per lane goes here, between the load block and the divergent early exit: with hipcc
-  // (ROCm 7.2) that keeps the two regions apart and the kernel allocates < 96 VGPRs (5 waves/SIMD, no spills)
-  // instead of ~130 (3 waves/SIMD).  It is clamped, never predicated.
-  if (FILL) fill_dst[min((uint32_t)wave * 64u + (uint32_t)lane, fill.total_quads - 1u)] = ones;
   if (!active) return;
 
   // ---- set-point for this env.step
@@ -245,6 +244,17 @@ __global__ __launch_bounds__(256) void snapshot_kernel(Params p) {
   p.snap[(size_t)sr.step() * p.Npad + env] = (uint32_t)v.egi(TE_E_STEP);
   p.snap[(size_t)sr.episode() * p.Npad + env] = (uint32_t)v.egi(TE_E_EPISODE);
   p.snap[(size_t)sr.done() * p.Npad + env] = 0u;
+}
+// rebuild slot_mask from the armed planes (after te_create / te_reset / te_set_state; during a rollout the
+// engage/observe kernel maintains it): one 64-thread block per chunk of 64 envs
+__global__ __launch_bounds__(64) void census_kernel(Params p) {
+  const int chunk = blockIdx.x, l = threadIdx.x, env = chunk * 64 + l;
+  uint32_t m = 0u;
+  for (int s = 0; s < p.D; ++s) {
+    const bool a = env < p.N && p.dstate[((size_t)TE_D_ARMED * p.D + s) * p.Npad + env] != 0u;
+    m |= (__ballot(a) != 0ull ? 1u : 0u) << s;
+  }
+  if (l == 0) p.slot_mask[chunk] = m;
 }
 // recompute the pending scripted commands from a freshly loaded state blob (te_set_state)
 __global__ __launch_bounds__(256) void prepare_commands_kernel(Params p) {
@@ -375,6 +385,14 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
   } else {
     emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, blockDim.x);
   }
+  if (threadIdx.x < kEPB) {  // which slots of this chunk the next sub-step launch has to fly (post-spawn flags)
+    uint32_t m = 0u;
+    for (int s = 0; s < p.D; ++s) {
+      const bool a = (int)threadIdx.x < nvalid && sm[(r.armed() + s) * kEPB + threadIdx.x] != 0u;
+      m |= (__ballot(a) != 0ull ? 1u : 0u) << s;
+    }
+    if (threadIdx.x == 0) p.slot_mask[blockIdx.x] = m;
+  }
   TE_STAMP(p, 500, 5);
   // terminal tiles of auto-reset envs (rare, block-uniform test): ones, drained, then patched
   const bool lane_done = threadIdx.x < kEPB && sm[r.done() * kEPB + threadIdx.x] != 0u;
@@ -486,12 +504,17 @@ struct te_env {
 };
 
 static thread_local std::string g_err;
+static void launch_census(te_env* e, hipStream_t st);
 static int fail(const std::string& m) { g_err = m; return 1; }
 #define TE_HIP(x)                                                                                      \
   do {                                                                                                 \
     hipError_t e_ = (x);                                                                               \
     if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));                  \
   } while (0)
+
+static void launch_census(te_env* e, hipStream_t st) {
+  hipLaunchKernelGGL(census_kernel, dim3(e->p.Npad / 64), dim3(64), 0, st, e->p);
+}
 
 struct DeviceGuard {
   int prev = -1; bool ok;
@@ -560,6 +583,12 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     delete e;
     return fail("te_create: hipMalloc failed");
   }
+  e->p.slot_mask = nullptr;
+  if (hipMalloc(&e->p.slot_mask, (size_t)(e->p.Npad / 64) * 4) != hipSuccess) {
+    (void)hipFree(e->p.dstate); (void)hipFree(e->p.estate);
+    delete e;
+    return fail("te_create: hipMalloc failed");
+  }
   e->p.snap = nullptr; e->p.ring = nullptr; e->p.entry_words = TE_RING_ENTRY_WORDS(D);
   if (cfg->stacked_obs) {
     e->stack_lds_bytes = (size_t)stack_lds_rows(D, cfg->n_pursuers) * kEPB * sizeof(uint32_t);
@@ -588,6 +617,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   launch_by_family(e->family, [&](auto fam) {
     hipLaunchKernelGGL((reset_kernel<decltype(fam)::value>), dim3(blocks), dim3(256), 0, nullptr, e->p, (const uint8_t*)nullptr);
   });
+  launch_census(e, nullptr);
   TE_HIP(hipGetLastError());
   TE_HIP(hipStreamSynchronize(nullptr));
   *out = e;
@@ -600,6 +630,7 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
   (void)hipFree(e->p.dstate);
   (void)hipFree(e->p.estate);
+  (void)hipFree(e->p.slot_mask);
   if (e->p.snap) (void)hipFree(e->p.snap);
   if (e->p.ring) (void)hipFree(e->p.ring);
   if (e->p.dbg) (void)hipFree(e->p.dbg);
@@ -613,6 +644,7 @@ __attribute__((visibility("default"))) int te_reset(te_env* e, const uint8_t* en
   launch_by_family(e->family, [&](auto fam) {
     hipLaunchKernelGGL((reset_kernel<decltype(fam)::value>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, e->p, env_mask);
   });
+  launch_census(e, (hipStream_t)stream);
   TE_HIP(hipGetLastError());
   return 0;
 }
@@ -653,8 +685,8 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   FillJob fill{nullptr, 0u, 0u};
   const size_t n_floats = (size_t)p.N * lidar_words_per_env;
   if (obs_lidar) {
-    const size_t quads = n_floats >> 2, first = (size_t)waves * 64;
-    if (quads > first && quads < (1ull << 32)) {
+    const size_t quads = n_floats >> 2;
+    if (quads >= 4096 && quads < (1ull << 32)) {
       fill = FillJob{obs_lidar, (uint32_t)quads, (uint32_t)e->n_fill_waves};
       if (n_floats & 3) hipLaunchKernelGGL(fill_ones_kernel, dim3(1), dim3(64), 0, st, obs_lidar + (quads << 2), n_floats & 3);
     } else {  // tiny or huge buffers: plain fill kernel first
@@ -768,6 +800,7 @@ __attribute__((visibility("default"))) int te_set_state(te_env* e, const void* s
     TE_HIP(hipMemcpyAsync(e->p.ring, (const uint32_t*)src_device + (need - ring_words(e)), ring_words(e) * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (e->family == FAM_LEVEL4)
     hipLaunchKernelGGL(prepare_commands_kernel, dim3((e->p.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->p);
+  launch_census(e, (hipStream_t)stream);
   TE_HIP(hipGetLastError());
   return 0;
 }
