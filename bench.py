@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--task", default="stage03", help="stage01 | stage02 | exp02 | stage03 (= exp03) | exp04")
+    ap.add_argument("--task", default="stage03", help="stage01 | stage02 | exp02 | stage03 (= exp03) | exp04 | level5 (stacked observation)")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--n-invaders", type=int, default=0, help="override I (stage02 with 8 invaders: --n-invaders 8)")
     ap.add_argument("--no-noise", action="store_true", help="motor noise off (parity runs); default on")
@@ -71,12 +71,13 @@ def cpu_baseline(task: str, overrides: dict, action_seed: int, seconds: float):
     cfg = O.default_config(task, n_envs=n, **overrides)
     env = O.OracleEnv(cfg, "f64", threads=cores)
     env.reset()
+    fn = env.step_stacked if cfg.stacked_obs else env.step
     for s in range(3):
-        env.step(env.random_actions(action_seed, s), terminal=False)
+        fn(env.random_actions(action_seed, s), terminal=False)
     t0 = time.perf_counter()
     steps = 0
     while True:
-        env.step(env.random_actions(action_seed, 3 + steps), terminal=False)
+        fn(env.random_actions(action_seed, 3 + steps), terminal=False)
         steps += 1
         if (time.perf_counter() - t0 >= seconds and steps >= 10) or steps >= 2000:
             break
@@ -128,12 +129,14 @@ def main():
         for i in range(n_total):
             env.random_actions(args.action_seed, i, out=actions[i])
 
+    step_fn = env.step_stacked if cfg.stacked_obs else env.step   # level5: te_step_stacked (third launch: stacked_kernel)
+
     def one_step(i: int):
         if pregen:
-            env.step(actions[i], terminal=True)
+            step_fn(actions[i], terminal=True)
         else:
             env.random_actions(args.action_seed, i, out=actions[0])
-            env.step(actions[0], terminal=True)
+            step_fn(actions[0], terminal=True)
 
     def armed_per_env() -> float:
         """Mean number of armed drones per env (disarmed slots are not flown: they cost one flag load)."""
@@ -182,8 +185,9 @@ def main():
         frac_window = 0.5 * n_events / max(args.steps, 1)
         armed = armed_begin + (armed_end - armed_begin) * frac_window
         per_drone = 2 * 176                                        # sub-step kernel: state read + written per armed drone
-        alg_k1 = armed * per_drone + 16 + 3 * 338 * 4              # + action + LIDAR background
-        alg_k2 = alg_all - (D * per_drone + 16 + 3 * 338 * 4)      # engage/observe kernel: the rest
+        lidar_bytes = (6 if cfg.stacked_obs else 1) * 3 * 338 * 4     # own sphere, or level5's six stacked spheres
+        alg_k1 = armed * per_drone + 16 + lidar_bytes              # + action + LIDAR background
+        alg_k2 = alg_all - (D * per_drone + 16 + lidar_bytes)      # engage/observe kernel (+ stacked_kernel in level5): the rest
         alg = alg_k1 + alg_k2
         out = {
             "metric": "env-steps/sec (whole job), random-action rollout",
@@ -191,7 +195,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.task} (level4 exp03-vFinal shape: {cfg.n_pursuers} pursuers + {cfg.n_invaders} "
-                                   f"invaders, own-sphere LIDAR 3x13x26), {n_local} envs per GPU, 16 physics sub-steps per env-step, "
+                                   f"invaders, {'stacked-sphere LIDAR 6x3x13x26' if cfg.stacked_obs else 'own-sphere LIDAR 3x13x26'}), {n_local} envs per GPU, 16 physics sub-steps per env-step, "
                                    f"random actions, motor noise {'on' if cfg.motor_noise else 'off'}, auto-reset on",
                        "task": args.task, "envs_per_gpu": n_local, "total_envs": world * n_local, "drones_per_env": D,
                        "parallelism": f"env-sharded x{world}, no collective"},
@@ -202,7 +206,7 @@ def main():
             ach = dom_bytes * n_local / (dom_ms * 1e-3) / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and args.task in ("stage03", "exp03") and n_local == 65536 and not args.n_invaders:  # what the PMC passes were taken on
                 try:
                     traffic = json.load(open(pmc)).get(dom_name, {}).get("hbm_bytes_per_launch")
                 except Exception:
