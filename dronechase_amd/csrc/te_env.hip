@@ -356,10 +356,19 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
     // critical path (D Philox draws + trigonometry + ~40 stores each, serially).
     const uint32_t my_task = threadIdx.x < kEPB ? sm[r.task() * kEPB + threadIdx.x] : 0u;
     if (__syncthreads_or(my_task != 0u)) {
-      for (int it = threadIdx.x; it < kEPB * p.D; it += blockDim.x) {
-        const int l = it & (kEPB - 1), s = it / kEPB;
+      // compact the flagged envs first (their lane numbers go to the front of the, now free, `lcell` row), so that the
+      // (env, slot) items spread over all 256 threads even when only a few envs of the block respawn
+      if (threadIdx.x < kEPB) {
+        const unsigned long long flagged = __ballot(my_task != 0u && (int)threadIdx.x < nvalid);
+        if (my_task != 0u && (int)threadIdx.x < nvalid)
+          sm[r.lcell() * kEPB + __popcll(flagged & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
+        if (threadIdx.x == 0) sm[r.lrhat() * kEPB] = (uint32_t)__popcll(flagged);  // slot 0 of lcell / lrhat is never a target: both rows are free
+      }
+      __syncthreads();
+      const int n_items = (int)sm[r.lrhat() * kEPB] * p.D;
+      for (int it = threadIdx.x; it < n_items; it += blockDim.x) {
+        const int s = it % p.D, l = (int)sm[r.lcell() * kEPB + it / p.D];
         const uint32_t t = sm[r.task() * kEPB + l];
-        if (t == 0u || l >= nvalid) continue;
         SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + l, r.P}, sm, l, r, p.D, r.P, env0 + l, false};
         level4_spawn_slot(p.cfg, v, s, (int)(t & 0xFFu), (uint32_t)v.egi(TE_E_EPISODE), (t >> 8) != 0u);
       }
