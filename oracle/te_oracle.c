@@ -1711,6 +1711,25 @@ OTE_API int ote_set_state(ote_env* E, const uint32_t* src) {
 }
 
 /* bare physics helper for analytic KATs: n sub-steps of ONE drone with a fixed set-point */
+/* the same, from a given z-velocity integrator (a drone that has hovered before: PID memories survive
+ * disarm / replace / arm, quadcopter.py:433-478), also returning the IMU read (body velocity, body rates) */
+OTE_API int ote_fly_from(const te_config* cfg, int mode, const double* setpoint, int n_substeps, const double* pos0,
+                         double zv_i0, double* out_pos, double* out_vel_body, double* out_euler, double* out_rate_body) {
+  ote_env E; memset(&E, 0, sizeof E);
+  E.cfg = *cfg; E.cfg.motor_noise = 0; E.D = 1;
+  ote_drone d; memset(&d, 0, sizeof d);
+  d.quat[3] = 1; d.armed = 1; d.zv_i = (real)zv_i0;
+  for (int k = 0; k < 3; ++k) d.pos[k] = (real)pos0[k];
+  for (int k = 0; k < 4; ++k) d.setpoint[k] = (real)setpoint[k];
+  for (int s = 0; s < n_substeps; ++s) {
+    substep(&E, 0, 0, &d, mode, 0, s);   /* observe() at its top leaves the IMU read of the state BEFORE this integration */
+    for (int k = 0; k < 3; ++k) {
+      out_pos[3 * s + k] = (double)d.obs_pos[k]; out_vel_body[3 * s + k] = (double)d.obs_vel[k];
+      out_euler[3 * s + k] = (double)d.obs_euler[k]; out_rate_body[3 * s + k] = (double)d.obs_rate[k];
+    }
+  }
+  return 0;
+}
 OTE_API int ote_fly(const te_config* cfg, int mode, const double* setpoint, int n_substeps, const double* pos0,
                     double* out_pos, double* out_vel, double* out_euler, double* out_throttle) {
   ote_env E; memset(&E, 0, sizeof E);

@@ -307,6 +307,15 @@ def fly(cfg, mode, setpoint, n_substeps, pos0, precision="f64"):
     return pos, vel, eul, thr
 
 
+def fly_from(cfg, mode, setpoint, n_substeps, pos0, zv_i0, precision="f64"):
+    """IMU reads (position, body velocity, euler, body rates) seen at the top of each of n sub-steps, starting at rest
+    with the z-velocity integrator pre-loaded."""
+    sp, p0 = _d(setpoint), _d(pos0)
+    out = [np.zeros((n_substeps, 3)) for _ in range(4)]
+    lib(precision).ote_fly_from(C.byref(cfg), C.c_int(mode), _p(sp), C.c_int(n_substeps), _p(p0), C.c_double(zv_i0), *[_p(o) for o in out])
+    return out
+
+
 def stack_draws(cfg: K.Config, env_local: int, episode: int, step: int, armed_pursuers: int) -> dict:
     """The random choices of one stacked observation: n, the chosen wingmen, their ages, the shuffle."""
     out = np.zeros(15, np.int32)

@@ -122,3 +122,43 @@ def test_f32_build_tracks_f64():
     p64, v64, e64, t64 = O.fly(cfg, 6, [0.4, -0.2, 0, 0.1], 16 * 30, [0, 0, 3], "f64")
     p32, v32, e32, t32 = O.fly(cfg, 6, [0.4, -0.2, 0, 0.1], 16 * 30, [0, 0, 3], "f32")
     assert np.abs(p64 - p32).max() < 2e-4 and np.abs(v64 - v32).max() < 2e-4
+
+
+def test_recorded_first_steps_weakly_constrain_the_physics():
+    """tests/golden/ref_level5_obs.npz holds the IMU reads of seven wingmen at two consecutive env-steps right after a
+    (re)spawn, each flying a constant BT command of 0.6 m/s (io_data0.h5, the only PyBullet + PyFlyt output in the
+    reference tree).  The hidden controller state at that moment is not recorded (PID memories survive a respawn,
+    quadcopter.py:433-478, so the z-velocity integrator sits near its hover value) and neither package can be run here,
+    so this is NOT a parity test: it pins signs and orders of magnitude of the restated cascade (lin-vel -> tilt ->
+    rate -> torque, z-vel -> thrust, motor lag) against real data.  Measured ratios recorded / restated: tilt 2.1-3.1x
+    after one step and 1.3-1.9x after two, body rates 1.2-2.1x, horizontal speed 2.1-3.8x: the real attitude loop is
+    faster than the UNVERIFIED cf2x table makes it."""
+    import os
+    from oracle import te_oracle as O
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_level5_obs.npz"))
+    I, A = g["inertial"].astype(np.float64), g["last_action"].astype(np.float64)
+    vel, eul, rate = I[:, 3:6] * (10 / 3.6), I[:, 6:9] * np.pi, I[:, 9:12] * 2 * np.pi
+    cfg = O.default_config("level5", n_envs=1)
+    q = cfg.quad
+    hover = float(np.sqrt(q.mass * q.gravity / q.total_thrust))
+    ratios = {"tilt1": [], "tilt2": [], "rate1": [], "speed1": []}
+    for w in range(7):
+        d = A[w, :3] / np.linalg.norm(A[w, :3])
+        assert abs(A[w, 3] - 0.6) < 1e-6
+        p, v, e, r = O.fly_from(cfg, 6, [0.6 * d[0], 0.6 * d[1], 0.0, 0.6 * d[2]], 32, [0, 0, 0], hover)
+        for step, (k, rec) in enumerate(((15, w), (31, w + 7)), start=1):
+            # the command's horizontal direction shows up with the right signs: roll = -y, pitch = +x (PX4 convention)
+            for axis in (0, 1):
+                if abs(eul[rec, axis]) > 0.01:
+                    assert np.sign(e[k, axis]) == np.sign(eul[rec, axis]), (w, step, axis)
+                if abs(vel[rec, axis]) > 0.005:
+                    assert np.sign(v[k, axis]) == np.sign(vel[rec, axis]), (w, step, axis)
+            tilt_rec, tilt_sim = np.hypot(*eul[rec, :2]), np.hypot(*e[k, :2])
+            ratios[f"tilt{step}"].append(tilt_rec / tilt_sim)
+            assert abs(eul[rec, 2]) < 0.01 and abs(e[k, 2]) < 0.01          # no yaw command, no yaw
+            assert abs(v[k, 2]) < 0.3 and abs(vel[rec, 2]) < 0.3            # near hover thrust from the first sub-steps
+        ratios["rate1"].append(np.hypot(*rate[w, :2]) / np.hypot(*r[15, :2]))
+        ratios["speed1"].append(np.hypot(*vel[w, :2]) / np.hypot(*v[15, :2]))
+    for name, (lo, hi) in {"tilt1": (1.5, 4.0), "tilt2": (1.0, 2.5), "rate1": (1.0, 3.0), "speed1": (1.5, 5.0)}.items():
+        x = np.array(ratios[name])
+        assert lo < x.min() and x.max() < hi, (name, x)
