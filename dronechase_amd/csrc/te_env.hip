@@ -514,6 +514,7 @@ struct te_env {
 
 static thread_local std::string g_err;
 static void launch_census(te_env* e, hipStream_t st);
+extern "C" __attribute__((visibility("default"))) void te_destroy(te_env* e);
 static int fail(const std::string& m) { g_err = m; return 1; }
 #define TE_HIP(x)                                                                                      \
   do {                                                                                                 \
@@ -569,6 +570,8 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   te_env* e = new (std::nothrow) te_env();
   if (!e) return fail("te_create: out of host memory");
   e->device = device_id;
+  e->p.dstate = nullptr; e->p.estate = nullptr; e->p.slot_mask = nullptr; e->p.snap = nullptr; e->p.ring = nullptr; e->p.dbg = nullptr;
+  auto bail = [&](const std::string& why) { te_destroy(e); return fail(why); };
   e->family = family_of(cfg->task);
   e->p.cfg = *cfg;
   e->p.kd = derive(*cfg);
@@ -583,37 +586,24 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     });
     if (le == hipSuccess)
       le = hipFuncSetAttribute(reinterpret_cast<const void*>(&observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
-    if (le != hipSuccess) { delete e; return fail(std::string("te_create: this many drones per env needs more LDS than a workgroup may have: ") + hipGetErrorString(le)); }
+    if (le != hipSuccess) return bail(std::string("te_create: this many drones per env needs more LDS than a workgroup may have: ") + hipGetErrorString(le));
   }
   const size_t dwords = (size_t)(TE_DRONE_WORDS + TE_X_WORDS) * D * e->p.Npad, ewords = (size_t)TE_ENV_WORDS * e->p.Npad;
-  if (dwords >= (1ull << 30)) { delete e; return fail("te_create: n_envs * drones too large for one te_env (state planes are indexed with 32 bits); shard it"); }
-  if (hipMalloc(&e->p.dstate, dwords * 4) != hipSuccess || hipMalloc(&e->p.estate, ewords * 4) != hipSuccess) {
-    if (e->p.dstate) (void)hipFree(e->p.dstate);
-    delete e;
-    return fail("te_create: hipMalloc failed");
-  }
-  e->p.slot_mask = nullptr;
-  if (hipMalloc(&e->p.slot_mask, (size_t)(e->p.Npad / 64) * 4) != hipSuccess) {
-    (void)hipFree(e->p.dstate); (void)hipFree(e->p.estate);
-    delete e;
-    return fail("te_create: hipMalloc failed");
-  }
-  e->p.snap = nullptr; e->p.ring = nullptr; e->p.entry_words = TE_RING_ENTRY_WORDS(D);
+  if (dwords >= (1ull << 30)) return bail("te_create: n_envs * drones too large for one te_env (state planes are indexed with 32 bits); shard it");
+  if (hipMalloc(&e->p.dstate, dwords * 4) != hipSuccess || hipMalloc(&e->p.estate, ewords * 4) != hipSuccess)
+    return bail("te_create: hipMalloc failed");
+  if (hipMalloc(&e->p.slot_mask, (size_t)(e->p.Npad / 64) * 4) != hipSuccess) return bail("te_create: hipMalloc failed");
+  e->p.entry_words = TE_RING_ENTRY_WORDS(D);
   if (cfg->stacked_obs) {
     e->stack_lds_bytes = (size_t)stack_lds_rows(D, cfg->n_pursuers) * kEPB * sizeof(uint32_t);
     const size_t snap_bytes = (size_t)snap_words(D, cfg->n_pursuers) * e->p.Npad * 4;
     const size_t ring_bytes = (size_t)cfg->n_envs * cfg->n_pursuers * TE_RING_DEPTH * e->p.entry_words * 4;
     hipError_t le = hipFuncSetAttribute(reinterpret_cast<const void*>(&stacked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->stack_lds_bytes);
-    if (le != hipSuccess || hipMalloc(&e->p.snap, snap_bytes) != hipSuccess || hipMalloc(&e->p.ring, ring_bytes) != hipSuccess) {
-      if (e->p.snap) (void)hipFree(e->p.snap);
-      (void)hipFree(e->p.dstate); (void)hipFree(e->p.estate);
-      delete e;
-      return fail("te_create: stacked observation buffers (ring / snapshot / LDS) could not be set up");
-    }
+    if (le != hipSuccess || hipMalloc(&e->p.snap, snap_bytes) != hipSuccess || hipMalloc(&e->p.ring, ring_bytes) != hipSuccess)
+      return bail("te_create: stacked observation buffers (ring / snapshot / LDS) could not be set up");
     TE_HIP(hipMemsetAsync(e->p.snap, 0, snap_bytes, nullptr));
     TE_HIP(hipMemsetAsync(e->p.ring, 0, ring_bytes, nullptr));
   }
-  e->p.dbg = nullptr;
 #ifdef TE_DEBUG_STAMPS
   const size_t dbg_words = 64 + 16 * (size_t)(e->p.Npad / kEPB + 1);
   if (hipMalloc(&e->p.dbg, dbg_words * sizeof(unsigned long long)) != hipSuccess) e->p.dbg = nullptr;
