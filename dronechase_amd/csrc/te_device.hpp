@@ -39,6 +39,9 @@ struct Params {
   uint32_t* dstate;
   uint32_t* estate;
   int N, Npad, D;
+  // staged row r of the engage/observe kernel lives at word stage_tab[r] & 0x7FFFFFFF of dstate (bit 31: of estate),
+  // env-fastest: filled once by te_create, read with scalar loads (the row index is wave-uniform)
+  uint32_t* stage_tab;
   // bit s of slot_mask[chunk] = some env of that chunk of 64 has drone s armed: written by the engage/observe launch
   // (and by reset / set_state), read by the sub-step launch with a SCALAR load, so that a wave with nothing to fly
   // retires without a single vector memory operation

@@ -36,29 +36,29 @@ struct GView {
 // LDS rows (kEPB words each) of the engage/observe kernel
 struct Rows {
   int D, P;
-  TE_DEV int I() const { return D - P; }
-  TE_DEV int obs_pos() const { return 0; }                  // 3*D : word-major, slot-minor
-  TE_DEV int armed() const { return 3 * D; }                // D   : ARMED
-  TE_DEV int munition() const { return 4 * D; }             // P   : MUNITION of the pursuers (nobody reads an invader's gun)
-  TE_DEV int last_fired() const { return 4 * D + P; }       // P   : LAST_FIRED of the pursuers
-  TE_DEV int agent() const { return 4 * D + 2 * P; }        // 9   : OBS_EULER, OBS_VEL, OBS_RATE of slot 0
-  TE_DEV int env() const { return agent() + 9; }            // TE_ENV_WORDS
-  TE_DEV int staged() const { return env() + TE_ENV_WORDS; }  // rows loaded from global memory
-  TE_DEV int rinv() const { return staged(); }              // 9   : inverse attitude of the agent (row-major)
-  TE_DEV int dpi() const { return rinv() + 9; }             // P*I : |obs_pos(p) - obs_pos(j)|
-  TE_DEV int zone() const { return dpi() + P * I(); }       // 1   : bit s = outside dome, bit 16+.. unused; see zone bits
-  TE_DEV int origin() const { return zone() + 1; }          // 1   : bit s = |obs_pos(s)| < origin_range
-  TE_DEV int lcell() const { return origin() + 1; }         // D   : LIDAR cell of drone j seen from the agent
-  TE_DEV int lrhat() const { return lcell() + D; }          // D   : normalised range of drone j
-  TE_DEV int hitmask() const { return lrhat() + D; }        // 1   : bit j = drone j owns its cell in this step's sphere
-  TE_DEV int done() const { return hitmask() + 1; }         // 1   : env auto-reset this step
-  TE_DEV int prevalid() const { return done() + 1; }        // 1   : distance / zone rows still valid after the logic
-  TE_DEV int task() const { return prevalid() + 1; }        // 1   : level4 spawn work left to the block: round | reset << 8
-  TE_DEV int smask() const { return task() + 1; }           // 1   : bit s = drone s armed when the block was staged
-  TE_DEV int anow() const { return smask() + 1; }           // 1   : bit s = drone s armed after the engagement (observation time)
-  TE_DEV int sstep() const { return smask() + 2; }          // 1   : RL step of this observation (the env record may be reset after it)
-  TE_DEV int sepis() const { return smask() + 3; }          // 1   : episode of this observation
-  TE_DEV int total() const { return sepis() + 1; }
+  __host__ __device__ __forceinline__ int I() const { return D - P; }
+  __host__ __device__ __forceinline__ int obs_pos() const { return 0; }                  // 3*D : word-major, slot-minor
+  __host__ __device__ __forceinline__ int armed() const { return 3 * D; }                // D   : ARMED
+  __host__ __device__ __forceinline__ int munition() const { return 4 * D; }             // P   : MUNITION of the pursuers (nobody reads an invader's gun)
+  __host__ __device__ __forceinline__ int last_fired() const { return 4 * D + P; }       // P   : LAST_FIRED of the pursuers
+  __host__ __device__ __forceinline__ int agent() const { return 4 * D + 2 * P; }        // 9   : OBS_EULER, OBS_VEL, OBS_RATE of slot 0
+  __host__ __device__ __forceinline__ int env() const { return agent() + 9; }            // TE_ENV_WORDS
+  __host__ __device__ __forceinline__ int staged() const { return env() + TE_ENV_WORDS; }  // rows loaded from global memory
+  __host__ __device__ __forceinline__ int rinv() const { return staged(); }              // 9   : inverse attitude of the agent (row-major)
+  __host__ __device__ __forceinline__ int dpi() const { return rinv() + 9; }             // P*I : |obs_pos(p) - obs_pos(j)|
+  __host__ __device__ __forceinline__ int zone() const { return dpi() + P * I(); }       // 1   : bit s = outside dome, bit 16+.. unused; see zone bits
+  __host__ __device__ __forceinline__ int origin() const { return zone() + 1; }          // 1   : bit s = |obs_pos(s)| < origin_range
+  __host__ __device__ __forceinline__ int lcell() const { return origin() + 1; }         // D   : LIDAR cell of drone j seen from the agent
+  __host__ __device__ __forceinline__ int lrhat() const { return lcell() + D; }          // D   : normalised range of drone j
+  __host__ __device__ __forceinline__ int hitmask() const { return lrhat() + D; }        // 1   : bit j = drone j owns its cell in this step's sphere
+  __host__ __device__ __forceinline__ int done() const { return hitmask() + 1; }         // 1   : env auto-reset this step
+  __host__ __device__ __forceinline__ int prevalid() const { return done() + 1; }        // 1   : distance / zone rows still valid after the logic
+  __host__ __device__ __forceinline__ int task() const { return prevalid() + 1; }        // 1   : level4 spawn work left to the block: round | reset << 8
+  __host__ __device__ __forceinline__ int smask() const { return task() + 1; }           // 1   : bit s = drone s armed when the block was staged
+  __host__ __device__ __forceinline__ int anow() const { return smask() + 1; }           // 1   : bit s = drone s armed after the engagement (observation time)
+  __host__ __device__ __forceinline__ int sstep() const { return smask() + 2; }          // 1   : RL step of this observation (the env record may be reset after it)
+  __host__ __device__ __forceinline__ int sepis() const { return smask() + 3; }          // 1   : episode of this observation
+  __host__ __device__ __forceinline__ int total() const { return sepis() + 1; }
 };
 __host__ __device__ inline int lds_rows(int D, int P) { return 6 * D + 2 * P + P * (D - P) + 9 + TE_ENV_WORDS + 9 + 10; }
 
