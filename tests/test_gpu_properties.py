@@ -142,3 +142,34 @@ def test_stage03_episode_statistics():
     assert int(touched.sum().item()) <= dones  # terminal rows only for envs that finished at least once
     assert int(touched.sum().item()) > 0
     env.close()
+
+
+def test_long_rollout_statistics_match_the_oracle():
+    """600 free-running steps of 4 096 stage03 envs on the GPU and in the oracle (same seeds, same actions).  Per-env
+    trajectories part ways after the first ambiguous decision (tests/test_gpu_parity.py handles that regime); the
+    POPULATION statistics must not: episode ends, kills, waves, rewards within a few percent."""
+    import numpy as np
+    torch = _torch()
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    from oracle import te_oracle as O
+    N, STEPS = 4096, 600
+    cfg = default_config("stage03", n_envs=N, motor_noise=1, seed=21)
+    g, o = BatchedEnv(cfg, "cuda:0"), O.OracleEnv(cfg, "f32", threads=8)
+    g.reset(); o.reset()
+    acc = {k: np.zeros(2) for k in ("dones", "reward", "agent_kills", "allies_kills", "deads", "wave")}
+    same_done = 0
+    for t in range(STEPS):
+        a = o.random_actions(77, t)
+        *_, ro, do, io = o.step(a)
+        *_, rg, dg, ig = g.step(torch.from_numpy(a).cuda())
+        dg_, rg_, ig_ = dg.cpu().numpy(), rg.cpu().numpy(), ig.cpu().numpy()
+        same_done += int((dg_ == do).sum())
+        for k, (x, y) in {"dones": (do.sum(), dg_.sum()), "reward": (ro.sum(), rg_.sum()), "agent_kills": (io[:, 0].sum(), ig_[:, 0].sum()),
+                          "allies_kills": (io[:, 1].sum(), ig_[:, 1].sum()), "deads": (io[:, 2].sum(), ig_[:, 2].sum()),
+                          "wave": (io[:, 3].sum(), ig_[:, 3].sum())}.items():
+            acc[k] += (float(x), float(y))
+    assert same_done > 0.97 * N * STEPS, same_done / (N * STEPS)
+    assert acc["dones"][0] > 1000         # enough episode ends for the comparison to mean something
+    for k, (x, y) in acc.items():
+        assert abs(x - y) <= 0.05 * max(abs(x), 1.0), (k, x, y)
