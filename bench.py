@@ -107,10 +107,17 @@ def main():
         build_library()  # no-op when dronechase_amd/libthreatengage.so is up to date
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: dronechase_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # TE_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
+    # devices round-robin; the reduction runs on host tensors).  The real thing is nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("TE_BENCH_BACKEND", "nccl")
+    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)  # barrier + max-over-ranks only; no data-path collective
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # barrier + max-over-ranks only; no data-path collective
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
 
     overrides = dict(motor_noise=0 if args.no_noise else 1, seed=args.seed)
@@ -168,7 +175,7 @@ def main():
     done_frac = float(env.done.float().mean().item())
     armed_end = armed_per_env() if rank == 0 else 0.0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
