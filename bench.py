@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--task", default="stage03", help="stage01 | stage02 | exp02 | stage03 (= exp03) | exp04 | level5 (stacked observation)")
+    ap.add_argument("--task", default="stage03", help="stage01 | stage02 | exp02 | stage03 (= exp03) | exp04 | level5 (stacked observation) | exp05 (ally observed + driven by the caller every step)")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--n-invaders", type=int, default=0, help="override I (stage02 with 8 invaders: --n-invaders 8)")
     ap.add_argument("--no-noise", action="store_true", help="motor noise off (parity runs); default on")
@@ -71,7 +71,15 @@ def cpu_baseline(task: str, overrides: dict, action_seed: int, seconds: float):
     cfg = O.default_config(task, n_envs=n, **overrides)
     env = O.OracleEnv(cfg, "f64", threads=cores)
     env.reset()
-    fn = env.step_stacked if cfg.stacked_obs else env.step
+    base_fn = env.step_stacked if cfg.stacked_obs else env.step
+    external = cfg.ally_policy == 3  # exp05: the ally's observation is built and its (synthetic) action applied every step
+
+    def fn(a, terminal=False, _n=[0]):
+        if external:
+            env.observe_ally()
+            env.set_ally_actions(env.random_actions(action_seed + 1000, _n[0]))
+            _n[0] += 1
+        return base_fn(a, terminal=terminal)
     for s in range(3):
         fn(env.random_actions(action_seed, s), terminal=False)
     t0 = time.perf_counter()
@@ -137,8 +145,23 @@ def main():
             env.random_actions(args.action_seed, i, out=actions[i])
 
     step_fn = env.step_stacked if cfg.stacked_obs else env.step   # level5: te_step_stacked (third launch: stacked_kernel)
+    # exp05: one env.step = te_observe_ally -> driver -> te_set_ally_actions -> te_step.  The driver here is synthetic
+    # (pre-generated random actions: the policy network is the caller's, not this library's), the observation is built
+    # every step all the same.
+    external = int(cfg.ally_policy) == 3
+    ally_actions = None
+    if external:
+        ally_actions = torch.empty((n_total if pregen else 1, n_local, 4), dtype=torch.float32, device=device)
+        if pregen:
+            for i in range(n_total):
+                env.random_actions(args.action_seed + 1000, i, out=ally_actions[i])
 
     def one_step(i: int):
+        if external:
+            env.observe_ally()
+            if not pregen:
+                env.random_actions(args.action_seed + 1000, i, out=ally_actions[0])
+            env.set_ally_actions(ally_actions[i if pregen else 0])
         if pregen:
             step_fn(actions[i], terminal=True)
         else:

@@ -110,6 +110,23 @@ class BatchedEnv:
                                           self._p(t[0]), self._p(t[1]), self._p(t[2]), self._p(t[3]), self._stream()), "te_step_stacked")
         return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
 
+    # exp05 ----------------------------------------------------------------------------------
+    def observe_ally(self):
+        """Observation of pursuer 1 on the current state (Exp05_vFinal_Task.compute_lw_observation,
+        exp05_vFinal_task.py:265-292): (lidar [N,3,13,26], inertial [N,15], last_action [N,4], active [N] u8)."""
+        if not hasattr(self, "ally_lidar"):
+            self.ally_lidar, self.ally_inertial = torch.empty_like(self.lidar), torch.empty_like(self.inertial)
+            self.ally_last_action = torch.empty_like(self.last_action)
+            self.ally_active = torch.empty((self.N,), dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.te_observe_ally(self._h, self._p(self.ally_lidar), self._p(self.ally_inertial), self._p(self.ally_last_action),
+                                          self._p(self.ally_active), self._stream()), "te_observe_ally")
+        return self.ally_lidar, self.ally_inertial, self.ally_last_action, self.ally_active
+
+    def set_ally_actions(self, actions: torch.Tensor) -> None:
+        """`pursuer.drive(action)` for every env whose ally is armed (exp05_vFinal_task.py:255-260)."""
+        a = self._check_actions(actions)
+        _lib.check(self.L.te_set_ally_actions(self._h, self._p(a), self._stream()), "te_set_ally_actions")
+
     def random_actions(self, seed: int, step_index: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty((self.N, 4), dtype=torch.float32, device=self.device)

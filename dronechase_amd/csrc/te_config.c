@@ -104,12 +104,13 @@ TE_API int te_config_default(te_config* c, int32_t task) {
       break;
     case TE_TASK_EXP03: /* exp03_vFinal_task.py:88-112 */
     case TE_TASK_EXP04: /* exp04_vFinal_task.py (ally frozen, bonus x10) */
+    case TE_TASK_EXP05: /* exp05_vFinal_task.py:99-124: the exp03 constants; the ally obeys a second policy (:252-260) */
       c->n_pursuers = 2; c->munition = 20;
       c->n_rounds = calculate_rounds(2, 20); c->n_invaders = c->n_rounds;
       c->dome_radius = 20.0f; c->lidar_radius = 40.0f;
       c->max_step = 300; c->pursuer_spawn_radius = 2.0f;
-      c->ally_policy = task == TE_TASK_EXP03 ? TE_ALLY_BT : TE_ALLY_FROZEN;
-      c->approach_bonus_gain = task == TE_TASK_EXP03 ? 1.0f : 10.0f;
+      c->ally_policy = task == TE_TASK_EXP03 ? TE_ALLY_BT : task == TE_TASK_EXP04 ? TE_ALLY_FROZEN : TE_ALLY_EXTERNAL;
+      c->approach_bonus_gain = task == TE_TASK_EXP04 ? 10.0f : 1.0f;
       break;
     case TE_TASK_LEVEL5: /* level5_task.py:76-98: the exp03 task logic with 6 wingmen, 12 invader slots, stacked observation */
       c->n_pursuers = 6; c->munition = 20; c->n_invaders = 12;
@@ -134,6 +135,9 @@ TE_API int te_algorithmic_bytes_per_env_step(const te_config* c, size_t* out) {
     size_t P = (size_t)c->n_pursuers, entry = (size_t)TE_RING_ENTRY_WORDS(D) * 4;
     *out += (size_t)(TE_STACK_SPHERES - 1) * TE_OBS_LIDAR_WORDS * 4 + TE_STACK_SPHERES + P * entry + 4 * entry;
   }
+  if (c->ally_policy == TE_ALLY_EXTERNAL)  /* exp05: the ally's observation (sphere + 15 + 4 floats + active byte) written, its action read,
+                                              the poses of all D drones read once more (7 words each), 11 words of the ally written */
+    *out += (size_t)TE_OBS_LIDAR_WORDS * 4 + 15 * 4 + 4 * 4 + 1 + 4 * 4 + D * 7 * 4 + 11 * 4;
   return 0;
 }
 

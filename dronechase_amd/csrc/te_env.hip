@@ -438,6 +438,71 @@ __global__ __launch_bounds__(256) void fill_ones_kernel(float* __restrict__ dst,
   for (size_t i = (quads << 2) + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_floats; i += stride) dst[i] = 1.0f;
 }
 
+// exp05: Exp05_vFinal_Task.compute_lw_observation (exp05_vFinal_task.py:265-292) of pursuer `me` = 1.  One thread per env,
+// straight from the state planes (coalesced over envs); the sphere's background was streamed by fill_ones_kernel on the
+// same stream, only the owner cells are patched here.  Same rules as the agent's sphere: every OTHER armed drone at its
+// last IMU position, seen from the ally's IMU attitude, closer wins in slot order, empty right after a reset.
+__global__ __launch_bounds__(256) void observe_ally_kernel(Params p, float* __restrict__ lidar, float* __restrict__ inertial,
+                                                           float* __restrict__ last_action, uint8_t* __restrict__ active) {
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env >= p.N) return;
+  const te_config& c = p.cfg;
+  const int me = 1, D = p.D;
+  const GView v{p.dstate, p.estate, D, p.Npad, env, c.n_pursuers};
+  const int step = v.egi(TE_E_STEP);
+  if (active) active[env] = v.gi(TE_D_ARMED, me) ? 1 : 0;
+  if (last_action)
+    reinterpret_cast<float4*>(last_action)[env] = make_float4(v.gf(TE_D_ALLY_ACTION, me), v.gf(TE_D_ALLY_ACTION + 1, me),
+                                                               v.gf(TE_D_ALLY_ACTION + 2, me), v.gf(TE_D_ALLY_ACTION + 3, me));
+  if (inertial) {
+    float in[TE_OBS_INERTIAL_WORDS];
+    inertial_obs(c, v, step, in, me);
+#pragma unroll
+    for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) inertial[(size_t)env * TE_OBS_INERTIAL_WORDS + k] = in[k];
+  }
+  if (!lidar || step == 0) return;
+  const Q4 q = quat_of_euler(V3{v.gf(TE_D_OBS_EULER, me), v.gf(TE_D_OBS_EULER + 1, me), v.gf(TE_D_OBS_EULER + 2, me)});
+  const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  const M3 R = rotation(Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2});
+  const V3 own = obs_pos(v, me);
+  uint32_t armed = 0;
+  for (int j = 0; j < D; ++j) armed |= (j != me && v.gi(TE_D_ARMED, j) ? 1u : 0u) << j;
+  // owner of a cell = smallest range, the earlier slot on ties (strict '<' in slot order, lidar_math.py:262-311); a
+  // feature clipped to 1.0 never enters an empty cell.  O(D^2) over a handful of armed drones, no per-thread arrays.
+  float* base = lidar + (size_t)env * TE_OBS_LIDAR_WORDS;
+  for (uint32_t todo = armed; todo; todo &= todo - 1) {
+    const int j = __ffs(todo) - 1;
+    int cell; float rhat;
+    lidar_cell(c, mul(R, sub(obs_pos(v, j), own)), cell, rhat);
+    if (!(rhat < 1.0f)) continue;
+    bool owner = true;
+    for (uint32_t rest = armed & ~(1u << j); rest && owner; rest &= rest - 1) {
+      const int k = __ffs(rest) - 1;
+      int ck; float rk;
+      lidar_cell(c, mul(R, sub(obs_pos(v, k), own)), ck, rk);
+      if (ck == cell && (rk < rhat || (rk == rhat && k < j))) owner = false;
+    }
+    if (!owner) continue;
+    base[cell] = rhat;
+    base[TE_LIDAR_CELLS + cell] = (float)(j < c.n_pursuers ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
+    base[2 * TE_LIDAR_CELLS + cell] = 0.1f;
+  }
+}
+// exp05: pursuer.drive(action) of drive_lw_rl_agent (exp05_vFinal_task.py:255-260; quadcopter.py:379-413) for armed allies
+__global__ __launch_bounds__(256) void set_ally_actions_kernel(Params p, const float* __restrict__ actions) {
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env >= p.N) return;
+  const int me = 1;
+  const GView v{p.dstate, p.estate, p.D, p.Npad, env, p.cfg.n_pursuers};
+  if (!v.gi(TE_D_ARMED, me)) return;
+  const float4 a = reinterpret_cast<const float4*>(actions)[env];
+  float vx, vy, vz;
+  command_to_velocity(a.x, a.y, a.z, a.w, vx, vy, vz);
+  v.sf(TE_X_CMD + 0, me, vx); v.sf(TE_X_CMD + 1, me, vy); v.sf(TE_X_CMD + 2, me, vz);
+  v.sf(TE_D_SETPOINT + 0, me, vx); v.sf(TE_D_SETPOINT + 1, me, vy); v.sf(TE_D_SETPOINT + 2, me, 0.0f); v.sf(TE_D_SETPOINT + 3, me, vz);
+  v.sf(TE_D_ALLY_ACTION + 0, me, a.x); v.sf(TE_D_ALLY_ACTION + 1, me, a.y); v.sf(TE_D_ALLY_ACTION + 2, me, a.z); v.sf(TE_D_ALLY_ACTION + 3, me, a.w);
+}
+
 // te_observe: current observation without stepping
 __global__ __launch_bounds__(256) void observe_kernel(Params p, ObsOut o) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
@@ -571,7 +636,9 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->n_envs < 1) return fail("te_create: n_envs < 1");
   if (cfg->n_pursuers < 1 || cfg->n_invaders < 1 || D > kMaxD) return fail("te_create: need 1 <= P, 1 <= I, P + I <= 32");
   if (cfg->substeps < 1 || cfg->substeps > 255) return fail("te_create: substeps out of range");
-  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_LEVEL5) return fail("te_create: unknown task");
+  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_EXP05) return fail("te_create: unknown task");
+  if (cfg->ally_policy == TE_ALLY_EXTERNAL && !(family_of(cfg->task) == FAM_LEVEL4 && cfg->n_pursuers == 2))
+    return fail("te_create: TE_ALLY_EXTERNAL (exp05) is the level4 task family with exactly 2 pursuers (exp05_vFinal_task.py:103)");
   if (cfg->stacked_obs && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: stacked_obs needs a level4-family task");
   if (cfg->task == TE_TASK_STAGE01 && !(cfg->n_pursuers == 2 && cfg->n_invaders == 1)) return fail("te_create: stage01 is 2 pursuers + 1 invader");
   if (cfg->lidar_radius <= 0.0f || cfg->dome_radius <= 0.0f || cfg->max_speed <= 0.0f) return fail("te_create: radii / max_speed must be positive");
@@ -667,6 +734,30 @@ __attribute__((visibility("default"))) int te_reset(te_env* e, const uint8_t* en
     hipLaunchKernelGGL((reset_kernel<decltype(fam)::value>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, e->p, env_mask);
   });
   launch_census(e, (hipStream_t)stream);
+  TE_HIP(hipGetLastError());
+  return 0;
+}
+
+__attribute__((visibility("default"))) int te_observe_ally(te_env* e, float* ally_lidar, float* ally_inertial, float* ally_last_action,
+                                                           uint8_t* ally_active, void* stream) {
+  if (!e) return fail("te_observe_ally: null env");
+  if (e->p.cfg.ally_policy != TE_ALLY_EXTERNAL) return fail("te_observe_ally: this te_env's ally is not driven by the caller (cfg.ally_policy != TE_ALLY_EXTERNAL)");
+  if ((ally_lidar && ((uintptr_t)ally_lidar & 15)) || (ally_last_action && ((uintptr_t)ally_last_action & 15)))
+    return fail("te_observe_ally: ally_lidar and ally_last_action must be 16-byte aligned");
+  DeviceGuard guard(e->device);
+  hipStream_t st = (hipStream_t)stream;
+  if (ally_lidar) hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, ally_lidar, (size_t)e->p.N * TE_OBS_LIDAR_WORDS);
+  hipLaunchKernelGGL(observe_ally_kernel, dim3((e->p.N + 255) / 256), dim3(256), 0, st, e->p, ally_lidar, ally_inertial, ally_last_action, ally_active);
+  TE_HIP(hipGetLastError());
+  return 0;
+}
+
+__attribute__((visibility("default"))) int te_set_ally_actions(te_env* e, const float* ally_actions, void* stream) {
+  if (!e) return fail("te_set_ally_actions: null env");
+  if (e->p.cfg.ally_policy != TE_ALLY_EXTERNAL) return fail("te_set_ally_actions: this te_env's ally is not driven by the caller (cfg.ally_policy != TE_ALLY_EXTERNAL)");
+  if (!ally_actions || ((uintptr_t)ally_actions & 15)) return fail("te_set_ally_actions: ally_actions ([N,4] f32, 16-byte aligned) is required");
+  DeviceGuard guard(e->device);
+  hipLaunchKernelGGL(set_ally_actions_kernel, dim3((e->p.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->p, ally_actions);
   TE_HIP(hipGetLastError());
   return 0;
 }

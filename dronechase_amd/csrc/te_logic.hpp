@@ -305,6 +305,7 @@ template <class V> TE_DEV void prepare_slot(const te_config& c, const V& v, int 
       cmd_toward(me, V3{v.gf(TE_D_FORMATION, s), v.gf(TE_D_FORMATION + 1, s), v.gf(TE_D_FORMATION + 2, s)}, c.ally_speed, out);
     }
   } else if (c.ally_policy != TE_ALLY_FROZEN) {  // (frozen: exp04_vFinal_task.py:240-242: drive([0,0,0,1]))
+    // nobody, or the caller's policy (te_set_ally_actions, exp05): the set-point persists
     out[0] = v.gf(TE_D_SETPOINT + 0, s); out[1] = v.gf(TE_D_SETPOINT + 1, s); out[2] = v.gf(TE_D_SETPOINT + 3, s);
   }
   v.sf(TE_X_CMD + 0, s, out[0]); v.sf(TE_X_CMD + 1, s, out[1]); v.sf(TE_X_CMD + 2, s, out[2]);
@@ -341,6 +342,10 @@ template <class V> TE_DEV void level4_spawn_slot(const te_config& c, const V& v,
   } else if (reset) {
     U4 r = env_rng(c, v.env, RNG_SPAWN_PURSUER, (uint32_t)s, 0, episode, 0);
     respawn_armed(c, v, s, level4_position(c, c.pursuer_spawn_radius, u01(r.x), u01(r.y)));
+    if (c.ally_policy == TE_ALLY_EXTERNAL && s == 1) {  // Exp05_vFinal_Task.init_globals: last_action = zeros (exp05_vFinal_task.py:139)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v.sf(TE_D_ALLY_ACTION + k, s, 0.0f);
+    }
   }
   v.si(TE_D_NAV_STATE, s, TE_NAV_WAIT);
 }
@@ -571,17 +576,17 @@ TE_DEV uint32_t resolve_hits(const SView& v, uint32_t armed_now) {
   return owners;
 }
 // normalize_inertial_data (level4/components/utils/normalization.py:6-30,61-110) + gun state
-template <class V> TE_DEV void inertial_obs(const te_config& c, const V& v, int step, float out[TE_OBS_INERTIAL_WORDS]) {
+template <class V> TE_DEV void inertial_obs(const te_config& c, const V& v, int step, float out[TE_OBS_INERTIAL_WORDS], int s = 0) {
   const float two_pi = 2.0f * kPi;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    out[0 + k] = clampf(v.gf(TE_D_OBS_POS + k, 0) / c.dome_radius, -1.0f, 1.0f);
-    out[3 + k] = clampf(v.gf(TE_D_OBS_VEL + k, 0) / c.max_speed, -1.0f, 1.0f);
-    out[6 + k] = clampf(v.gf(TE_D_OBS_EULER + k, 0) / kPi, -1.0f, 1.0f);
-    out[9 + k] = clampf(v.gf(TE_D_OBS_RATE + k, 0) / two_pi, -1.0f, 1.0f);
+    out[0 + k] = clampf(v.gf(TE_D_OBS_POS + k, s) / c.dome_radius, -1.0f, 1.0f);
+    out[3 + k] = clampf(v.gf(TE_D_OBS_VEL + k, s) / c.max_speed, -1.0f, 1.0f);
+    out[6 + k] = clampf(v.gf(TE_D_OBS_EULER + k, s) / kPi, -1.0f, 1.0f);
+    out[9 + k] = clampf(v.gf(TE_D_OBS_RATE + k, s) / two_pi, -1.0f, 1.0f);
   }
   float g[3];
-  gun_state(c, v.gi(TE_D_MUNITION, 0), v.gi(TE_D_LAST_FIRED, 0), step, max_munition_of(c, 0), g);
+  gun_state(c, v.gi(TE_D_MUNITION, s), v.gi(TE_D_LAST_FIRED, s), step, max_munition_of(c, s), g);
   out[12] = g[0]; out[13] = g[1]; out[14] = g[2];
 }
 TE_DEV void write_obs_rows(const ObsOut& o, int env, const float inertial[TE_OBS_INERTIAL_WORDS], const float la[4]) {

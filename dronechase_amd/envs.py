@@ -69,6 +69,29 @@ class Exp04vFinalEnvironment(_SingleEnv):  # level4/exp04_vFinal_environment.py:
     TASK = "exp04"
 
 
+class Exp05vFinalEnvironment(_SingleEnv):  # level4/exp05_vFinal_environment.py
+    """exp03 with the ally flown by a second policy.  `update_model(model)` (exp05_vFinal_environment.py:103-104) takes
+    anything with SB3's `predict(observation, deterministic=True) -> (action, state)`; as in the reference
+    (Exp05_vFinal_Task.drive_lw_rl_agent, exp05_vFinal_task.py:252-260) it is asked once per step, before the physics,
+    with the ally's own observation, and stepping without a model is an error (the reference raises AttributeError)."""
+    TASK = "exp05"
+
+    def update_model(self, model) -> None:
+        self.lw_driver = model
+
+    def step(self, rl_action: np.ndarray):
+        import torch
+
+        if not hasattr(self, "lw_driver"):
+            raise AttributeError("Exp05vFinalEnvironment.step before update_model(model): the ally has no driver")
+        lidar, inertial, last_action, active = self._b.observe_ally()
+        if bool(active[0].item()):
+            obs = {"lidar": lidar[0].cpu().numpy(), "inertial_data": inertial[0].cpu().numpy(), "last_action": last_action[0].cpu().numpy()}
+            action, _ = self.lw_driver.predict(obs, deterministic=True)
+            self._b.set_ally_actions(torch.as_tensor(np.asarray(action, np.float32).reshape(1, 4), device=self._b.device))
+        return super().step(rl_action)
+
+
 class PyflytL2EnviromentModifiedV2(_SingleEnv):  # level2/pyflyt_level2_environment_modified_v2.py:15 (sic)
     TASK = "stage01"
     DEFAULT_DOME = 10.0
@@ -83,5 +106,5 @@ class Level5Environment(_SingleEnv):  # threatsense/level5/level5_envrionment.py
     TASK = "level5"
 
 
-ENV_TASKS = {cls: cls.TASK for cls in (Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment,
+ENV_TASKS = {cls: cls.TASK for cls in (Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment,
                                        PyflytL2EnviromentModifiedV2, PyflytL3EnviromentV2, Level5Environment)}

@@ -60,6 +60,25 @@ class LidarInertialActionPolicy(nn.Module):
         return torch.distributions.Normal(mu, self.log_std.exp().expand_as(mu)), v
 
 
+class PolicyDriver:
+    """SB3-style `predict` over a LidarInertialActionPolicy, on the device: what ThreatEngageVecEnv.update_model (exp05:
+    the ally flown by a copy of the learning policy, apps/threatengage_runner/stage03/experiments/05/
+    bo_exp05_vFinal_home_office_app.py:140,179) takes when the observations should not leave HBM."""
+    accepts_torch = True
+
+    def __init__(self, policy: nn.Module):
+        self.policy = policy
+        self.low = None
+
+    @torch.no_grad()
+    def predict(self, observation: Dict[str, torch.Tensor], state=None, episode_start=None, deterministic: bool = True):
+        dist, _ = self.policy.dist(observation)
+        a = dist.mean if deterministic else dist.sample()
+        if self.low is None:
+            self.low = torch.tensor([-1.0, -1.0, -1.0, 0.0], device=a.device)
+        return torch.max(torch.min(a, torch.ones_like(a)), self.low), None
+
+
 @dataclass
 class PPOConfig:
     n_steps: int = 128

@@ -90,6 +90,9 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
         self._seeds: List[Optional[int]] = [None] * self.num_envs
         self._options: List[Dict[str, Any]] = [{} for _ in range(self.num_envs)]
         self.metadata = {"render_modes": []}
+        # exp05: the ally's driver (exp05_vFinal_environment.py:103-104); set with update_model / env_method("update_model", m)
+        self.external_ally = int(self.cfg.ally_policy) == K.ALLY_EXTERNAL
+        self.lw_driver = None
 
     # ------------------------------------------------------------------ helpers
     def _to_out(self, t):
@@ -129,6 +132,8 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
         if self._actions is None:
             raise RuntimeError("step_wait() without step_async()")
         b = self.backend
+        if self.external_ally:
+            self._drive_ally()
         *obs_t, reward, done, info = (b.step_stacked if self.stacked else b.step)(self._actions, terminal=True)
         self._actions = None
         obs = self._obs(*obs_t)
@@ -158,6 +163,28 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
         self.step_async(actions)
         return self.step_wait()
 
+    # ------------------------------------------------------------------ exp05
+    def update_model(self, model) -> None:
+        """The ally's policy: SB3's `predict(observation, deterministic=True) -> (actions [N,4], state)` on the batched
+        observation dict of the allies.  A driver with a true `accepts_torch` attribute gets device tensors (no host
+        copy: dronechase_amd.ppo.PolicyDriver); anything else gets numpy arrays, like an SB3 model."""
+        if not self.external_ally:
+            raise AttributeError("update_model: only exp05 (cfg.ally_policy == ALLY_EXTERNAL) has an ally driver")
+        self.lw_driver = model
+
+    def _drive_ally(self) -> None:
+        # Exp05_vFinal_Task.drive_lw_rl_agent (exp05_vFinal_task.py:252-260), for all envs at once
+        if self.lw_driver is None:
+            raise AttributeError("exp05: step before update_model(model): the ally has no driver")
+        import torch
+
+        lidar, inertial, last_action, _active = self.backend.observe_ally()
+        obs = {"lidar": lidar, "inertial_data": inertial, "last_action": last_action}
+        if not getattr(self.lw_driver, "accepts_torch", False):
+            obs = {k: v.detach().cpu().numpy() for k, v in obs.items()}
+        actions, _ = self.lw_driver.predict(obs, deterministic=True)
+        self.backend.set_ally_actions(self._as_device_actions(actions).contiguous())
+
     def close(self) -> None:
         if self.backend is not None:
             self.backend.close()
@@ -186,6 +213,9 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
         raise AttributeError(f"per-env attribute {attr_name!r} cannot be set on a batched environment")
 
     def env_method(self, method_name: str, *method_args, indices=None, **method_kwargs) -> List[Any]:
+        if method_name == "update_model" and self.external_ally:  # one driver for the whole batch
+            self.update_model(*method_args, **method_kwargs)
+            return [None] * len(list(self._indices(indices)))
         raise AttributeError(f"per-env method {method_name!r} is not available on a batched environment")
 
     def env_is_wrapped(self, wrapper_class, indices=None) -> List[bool]:

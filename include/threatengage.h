@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TE_ABI_VERSION 2
+#define TE_ABI_VERSION 3
 
 /* ---- tasks (reference env class each one mirrors) ----------------------- */
 enum {
@@ -40,12 +40,15 @@ enum {
   TE_TASK_EXP02 = 3,   /* level4/exp02_vFinal_environment.py + tasks/exp02_vFinal_task.py */
   TE_TASK_EXP03 = 4,   /* level4/exp03_vFinal_environment.py + tasks/exp03_vFinal_task.py (apps stage03) */
   TE_TASK_EXP04 = 5,   /* level4/exp04_vFinal_environment.py (ally frozen, x10 approach bonus) */
-  TE_TASK_LEVEL5 = 6   /* threatsense/level5/level5_envrionment.py + tasks/level5_task.py: the exp03 task with 6 pursuers,
+  TE_TASK_LEVEL5 = 6,  /* threatsense/level5/level5_envrionment.py + tasks/level5_task.py: the exp03 task with 6 pursuers,
                           12 invaders and the FusedLIDAR stacked-sphere observation (te_step_stacked) */
+  TE_TASK_EXP05 = 7    /* level4/exp05_vFinal_environment.py + tasks/exp05_vFinal_task.py: exp03 with the ally driven by a
+                          second policy (drive_lw_rl_agent, :252-260): te_observe_ally / te_set_ally_actions */
 };
 
-/* ally (pursuer slots >= 1) policy */
-enum { TE_ALLY_NONE = 0, TE_ALLY_BT = 1, TE_ALLY_FROZEN = 2 };
+/* ally (pursuer slots >= 1) policy: nobody (the set-point persists), LoyalWingmanBehaviorTree, drive([0,0,0,1]) every
+ * step (exp04), or the caller through te_set_ally_actions (exp05; n_pursuers must be 2, exp05_vFinal_task.py:103) */
+enum { TE_ALLY_NONE = 0, TE_ALLY_BT = 1, TE_ALLY_FROZEN = 2, TE_ALLY_EXTERNAL = 3 };
 
 /* kamikaze FSM states (core/entities/navigators/loitering_munition_navigator_air_combat_only.py:138-246) */
 enum { TE_NAV_WAIT = 0, TE_NAV_COLLIDE_WINGMAN = 1, TE_NAV_COLLIDE_BUILDING = 2 };
@@ -172,6 +175,8 @@ enum {
   TE_D_FORMATION = 45, /* 3  last replace() position (quadcopter.py:437) */
   TE_D_PENDING = 48,   /* 6  world force(3)+torque(3) applied outside the loop, consumed by the next
                              integration (stage01 replace_invader, level2/components/quadcopter_manager.py:166-179) */
+  TE_D_ALLY_ACTION = 48, /* 4  the same words of pursuer 1 under TE_ALLY_EXTERNAL (no level4 drone has a pending wrench):
+                             the ally policy's previous action, Exp05_vFinal_Task.last_action (exp05_vFinal_task.py:139,259) */
   TE_D_ARMED = 54,     /* i32 */
   TE_D_MUNITION = 55,  /* i32 */
   TE_D_LAST_FIRED = 56,/* i32 */
@@ -239,6 +244,19 @@ int te_step_stacked(te_env* env, const float* actions, float* obs_stacked, uint8
                     uint8_t* terminal_mask, float* terminal_inertial, float* terminal_last_action, void* stream);
 int te_observe_stacked(te_env* env, float* obs_stacked, uint8_t* obs_mask, float* obs_inertial, float* obs_last_action,
                        void* stream);
+
+/* exp05 (cfg.ally_policy == TE_ALLY_EXTERNAL): the two halves of Exp05_vFinal_Task.drive_lw_rl_agent
+ * (exp05_vFinal_task.py:252-260), which the reference runs in on_step_start, i.e. BEFORE the physics of a step:
+ *   te_observe_ally      = compute_lw_observation (:265-292) of pursuer 1 on the CURRENT state: its own LIDAR sphere
+ *                          ally_lidar [N,3,13,26], normalised inertial data + gun state ally_inertial [N,15], the ally
+ *                          policy's previous action ally_last_action [N,4] (zeros after a reset); ally_active [N] u8 = 1
+ *                          where the reference would call driver.predict (the ally is armed).  Any pointer may be NULL.
+ *   te_set_ally_actions  = pursuer.drive(action) for every env whose ally is armed: ally_actions [N,4] f32 as te_step's
+ *                          actions; remembered as the ally's last action.  Rows of envs with a dead ally are ignored.
+ * One env.step of exp05 is therefore te_observe_ally -> (the caller's policy) -> te_set_ally_actions -> te_step. */
+int te_observe_ally(te_env* env, float* ally_lidar, float* ally_inertial, float* ally_last_action, uint8_t* ally_active,
+                    void* stream);
+int te_set_ally_actions(te_env* env, const float* ally_actions, void* stream);
 
 /* Synthetic random-action generator of the throughput harness
  * (apps/threatengage_runner/interactive/analyse.py:55-59): dir ~ U(-1,1)^3, mag ~ U(0,1),

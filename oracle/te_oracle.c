@@ -61,6 +61,7 @@ typedef struct {
   int32_t episode;
   real last_action[4];
   real prev_snap_min;
+  real ally_action[4]; /* TE_ALLY_EXTERNAL: Exp05_vFinal_Task.last_action (exp05_vFinal_task.py:139,259); blob: TE_D_ALLY_ACTION of pursuer 1 */
 } ote_envrec;
 
 typedef struct ote_env {
@@ -1031,6 +1032,7 @@ static void level4_reset_env(ote_env* E, int e) {
   er->agent_kills = 0; er->allies_kills = 0; er->deads = 0;
   er->last_dist = (real)c->dome_radius;
   for (int k = 0; k < 4; ++k) er->last_action[k] = 0;
+  for (int k = 0; k < 4; ++k) er->ally_action[k] = 0; /* exp05_vFinal_task.py:139 (init_globals) */
   for (int i = 0; i < E->D; ++i) disarm(&dr[i]);
   /* on_episode_start */
   level4_setup_round(E, e, er->round);
@@ -1567,6 +1569,39 @@ OTE_API int ote_observe(ote_env* E, float* lidar, float* inertial, float* last_a
   }
   return 0;
 }
+/* exp05: Exp05_vFinal_Task.compute_lw_observation (exp05_vFinal_task.py:265-292) of pursuer 1 on the current state,
+ * and the `pursuer.drive(action)` half of drive_lw_rl_agent (:252-260).  The reference loops over
+ * get_armed_pursuers()[1:]; the agent is armed at every step boundary (its death ends the episode), so the ally is
+ * driven exactly when it is armed. */
+OTE_API int ote_observe_ally(ote_env* E, float* lidar, float* inertial, float* last_action, uint8_t* active) {
+  const te_config* c = &E->cfg;
+  if (c->ally_policy != TE_ALLY_EXTERNAL || c->n_pursuers != 2) return 1;
+  for (int e = 0; e < c->n_envs; ++e) {
+    ote_drone* dr = &E->drones[(size_t)e * E->D];
+    ote_envrec* er = &E->envs[e];
+    if (lidar) {
+      float* L = lidar + (size_t)e * TE_OBS_LIDAR_WORDS;
+      if (er->step == 0) for (int i = 0; i < TE_OBS_LIDAR_WORDS; ++i) L[i] = 1.0f; /* as ote_observe */
+      else own_sphere(c, dr, E->D, 1, L);
+    }
+    if (inertial) inertial_obs(c, &dr[1], er->step, max_munition_of(c, 1), inertial + (size_t)e * TE_OBS_INERTIAL_WORDS);
+    if (last_action) for (int k = 0; k < 4; ++k) last_action[(size_t)e * 4 + k] = (float)er->ally_action[k];
+    if (active) active[e] = dr[1].armed ? 1 : 0;
+  }
+  return 0;
+}
+OTE_API int ote_set_ally_actions(ote_env* E, const float* actions) {
+  const te_config* c = &E->cfg;
+  if (c->ally_policy != TE_ALLY_EXTERNAL || c->n_pursuers != 2) return 1;
+  for (int e = 0; e < c->n_envs; ++e) {
+    ote_drone* dr = &E->drones[(size_t)e * E->D];
+    if (!dr[1].armed) continue;
+    real cmd[4];
+    for (int k = 0; k < 4; ++k) { cmd[k] = (real)actions[(size_t)e * 4 + k]; E->envs[e].ally_action[k] = cmd[k]; }
+    command_to_setpoint(cmd, dr[1].setpoint);
+  }
+  return 0;
+}
 OTE_API int ote_step(ote_env* E, const float* actions, float* lidar, float* inertial, float* last_action, float* reward,
                      uint8_t* done, int32_t* info, float* t_lidar, float* t_inertial, float* t_last_action, int threads) {
   const int N = E->cfg.n_envs;
@@ -1676,6 +1711,8 @@ OTE_API int ote_get_state(const ote_env* E, uint32_t* dst) {
     w[TE_E_DEADS] = (uint32_t)r->deads; w[TE_E_SNAP_MASK] = r->snap_mask; w[TE_E_EPISODE] = (uint32_t)r->episode;
     put_f(w, TE_E_LAST_ACTION, r->last_action, 4); put_f(w, TE_E_PREV_SNAP_MIN, &r->prev_snap_min, 1);
   }
+  if (E->cfg.ally_policy == TE_ALLY_EXTERNAL)  /* the ally policy's last action lives in pursuer 1's TE_D_ALLY_ACTION words */
+    for (int e = 0; e < E->cfg.n_envs; ++e) put_f(dst + ((size_t)e * E->D + 1) * TE_DRONE_WORDS, TE_D_ALLY_ACTION, E->envs[e].ally_action, 4);
   if (E->ring) memcpy(base + (size_t)E->cfg.n_envs * TE_ENV_WORDS, E->ring, ring_words(E) * sizeof(uint32_t));
   return 0;
 }
@@ -1706,6 +1743,11 @@ OTE_API int ote_set_state(ote_env* E, const uint32_t* src) {
     r->deads = (int32_t)w[TE_E_DEADS]; r->snap_mask = w[TE_E_SNAP_MASK]; r->episode = (int32_t)w[TE_E_EPISODE];
     get_f(w, TE_E_LAST_ACTION, r->last_action, 4); get_f(w, TE_E_PREV_SNAP_MIN, &r->prev_snap_min, 1);
   }
+  if (E->cfg.ally_policy == TE_ALLY_EXTERNAL)
+    for (int e = 0; e < E->cfg.n_envs; ++e) {
+      get_f(src + ((size_t)e * E->D + 1) * TE_DRONE_WORDS, TE_D_ALLY_ACTION, E->envs[e].ally_action, 4);
+      for (int k = 0; k < 6; ++k) E->drones[(size_t)e * E->D + 1].pending[k] = 0;  /* not a wrench in this layout */
+    }
   if (E->ring) memcpy(E->ring, base + (size_t)E->cfg.n_envs * TE_ENV_WORDS, ring_words(E) * sizeof(uint32_t));
   return 0;
 }

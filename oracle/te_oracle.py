@@ -44,6 +44,8 @@ def lib(precision: str = "f64") -> C.CDLL:
         L.ote_ring_lookup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.ote_step_stacked.argtypes = [C.c_void_p] + [C.c_void_p] * 12 + [C.c_int]
         L.ote_observe_stacked.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.ote_observe_ally.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.ote_set_ally_actions.argtypes = [C.c_void_p, C.c_void_p]
         L.ote_stack_draws.argtypes = [C.POINTER(K.Config), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
         L.ote_state_margins.argtypes = [C.c_void_p, C.c_void_p]
         L.ote_random_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
@@ -140,6 +142,21 @@ class OracleEnv:
                                      self.threads)
         assert rc == 0
         return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
+
+    # exp05 ----------------------------------------------------------------------------------
+    def observe_ally(self):
+        """(lidar [N,3,13,26], inertial [N,15], last_action [N,4], active [N] u8) of pursuer 1 on the current state."""
+        lidar, inertial = np.empty_like(self.lidar), np.empty_like(self.inertial)
+        last_action, active = np.empty_like(self.last_action), np.empty(self.N, np.uint8)
+        rc = self.L.ote_observe_ally(self.h, _p(lidar), _p(inertial), _p(last_action), _p(active))
+        assert rc == 0, "observe_ally needs cfg.ally_policy == ALLY_EXTERNAL with 2 pursuers"
+        return lidar, inertial, last_action, active
+
+    def set_ally_actions(self, actions: np.ndarray):
+        a = np.ascontiguousarray(actions, np.float32)
+        assert a.shape == (self.N, 4)
+        rc = self.L.ote_set_ally_actions(self.h, _p(a))
+        assert rc == 0, "set_ally_actions needs cfg.ally_policy == ALLY_EXTERNAL with 2 pursuers"
 
     def stack_margins(self) -> np.ndarray:
         """Smallest angular distance (rad) of any feature binned during the last step to a LIDAR cell boundary."""

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 STATE_TOL = 1e-4
 OBS_TOL = 1e-5
 MARGIN = 1e-4
-TASKS = [("exp03", {}), ("exp02", {}), ("exp04", {}), ("stage02", {}), ("stage02", {"n_invaders": 8}), ("stage01", {})]
+TASKS = [("exp03", {}), ("exp02", {}), ("exp04", {}), ("exp05", {}), ("stage02", {}), ("stage02", {"n_invaders": 8}), ("stage01", {})]
 
 
 def _gpu():
