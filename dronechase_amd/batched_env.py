@@ -127,6 +127,14 @@ class BatchedEnv:
         a = self._check_actions(actions)
         _lib.check(self.L.te_set_ally_actions(self._h, self._p(a), self._stream()), "te_set_ally_actions")
 
+    def wingman_info(self) -> torch.Tensor:
+        """[N,P,5] i32 rows (lw_kills, lw_alive, lw_munitions, current_wave, step) of every pursuer
+        (Evaluation_Task.compute_info, evaluation_task.py:553-574); cfg.evaluation only."""
+        if not hasattr(self, "_wingman_info"):
+            self._wingman_info = torch.empty((self.N, int(self.cfg.n_pursuers), 5), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.te_wingman_info(self._h, self._p(self._wingman_info), self._stream()), "te_wingman_info")
+        return self._wingman_info
+
     def random_actions(self, seed: int, step_index: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty((self.N, 4), dtype=torch.float32, device=self.device)

@@ -9,9 +9,9 @@ import ctypes as C
 
 TE_ABI_VERSION = 3
 
-TASK_STAGE01, TASK_STAGE02, TASK_EXP02, TASK_EXP03, TASK_EXP04, TASK_LEVEL5, TASK_EXP05 = 1, 2, 3, 4, 5, 6, 7
+TASK_STAGE01, TASK_STAGE02, TASK_EXP02, TASK_EXP03, TASK_EXP04, TASK_LEVEL5, TASK_EXP05, TASK_EVALUATION = 1, 2, 3, 4, 5, 6, 7, 8
 TASKS = {"stage01": TASK_STAGE01, "stage02": TASK_STAGE02, "exp02": TASK_EXP02, "exp03": TASK_EXP03,
-         "stage03": TASK_EXP03, "exp04": TASK_EXP04, "level5": TASK_LEVEL5, "exp05": TASK_EXP05}
+         "stage03": TASK_EXP03, "exp04": TASK_EXP04, "level5": TASK_LEVEL5, "exp05": TASK_EXP05, "evaluation": TASK_EVALUATION}
 ALLY_NONE, ALLY_BT, ALLY_FROZEN, ALLY_EXTERNAL = 0, 1, 2, 3
 
 LIDAR_NTHETA, LIDAR_NPHI, LIDAR_CHANNELS = 13, 26, 3
@@ -34,7 +34,7 @@ def ring_entry_words(n_drones: int) -> int:
 # word offsets inside a drone record of the state blob (TE_D_*)
 D = dict(POS=0, QUAT=3, VEL=7, OMEGA=10, THROTTLE=13, PID_AV_I=17, PID_AV_E=20, PID_LV_I=23, PID_LV_E=25,
          PID_ZV_I=27, PID_ZV_E=28, SETPOINT=29, OBS_POS=33, OBS_EULER=36, OBS_VEL=39, OBS_RATE=42, FORMATION=45,
-         PENDING=48, ALLY_ACTION=48, ARMED=54, MUNITION=55, LAST_FIRED=56, NAV_STATE=57)
+         PENDING=48, ALLY_ACTION=48, ARMED=54, MUNITION=55, LAST_FIRED=56, NAV_STATE=57, KILLS=57)
 # word offsets inside an env record (TE_E_*)
 E = dict(STEP=0, MAX_STEP=1, ROUND=2, LAST_DIST=3, AGENT_KILLS=4, ALLIES_KILLS=5, DEADS=6, SNAP_MASK=7, EPISODE=8,
          LAST_ACTION=9, PREV_SNAP_MIN=13)
@@ -73,7 +73,7 @@ class Config(C.Structure):
         ("ally_speed", C.c_float), ("ally_policy", C.c_int32), ("approach_bonus_gain", C.c_float),
         ("catch_distance", C.c_float), ("building_position", C.c_float * 3),
         ("motor_noise", C.c_int32), ("auto_reset", C.c_int32), ("kamikaze_cone_check", C.c_int32), ("stacked_obs", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("evaluation", C.c_int32), ("reserved", C.c_int32 * 3),
         ("quad", QuadParams),
     ]
 

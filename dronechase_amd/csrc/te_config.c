@@ -120,6 +120,15 @@ TE_API int te_config_default(te_config* c, int32_t task) {
       c->ally_policy = TE_ALLY_BT; c->approach_bonus_gain = 1.0f;
       c->stacked_obs = 1;
       break;
+    case TE_TASK_EVALUATION: /* evaluation_task.py:89-112: one behaviour-tree driver (evaluation_exp01_1bt_app_ready.py:66-68),
+                                TIME_IS_LIMITED False (max_step 0 = no limit), the exp03 constants otherwise */
+      c->n_pursuers = 1; c->munition = 20;
+      c->n_rounds = calculate_rounds(1, 20); c->n_invaders = c->n_rounds;
+      c->dome_radius = 20.0f; c->lidar_radius = 40.0f;
+      c->max_step = 0; c->pursuer_spawn_radius = 2.0f;
+      c->ally_policy = TE_ALLY_BT; c->approach_bonus_gain = 1.0f;
+      c->evaluation = 1;
+      break;
     default:
       return 2;
   }
@@ -142,3 +151,4 @@ TE_API int te_algorithmic_bytes_per_env_step(const te_config* c, size_t* out) {
 }
 
 TE_API int te_abi_version(void) { return TE_ABI_VERSION; }
+TE_API int te_calculate_rounds(int32_t defenders, int32_t munition) { return calculate_rounds(defenders, munition); }

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   V3 pf{0, 0, 0}, pt{0, 0, 0};
   uint32_t episode = 0, step_index = 0;
   if (active) {
-    if (slot == 0) act = reinterpret_cast<const float4*>(actions)[env];
+    const bool scripted0 = FAMILY == FAM_LEVEL4 && c.evaluation != 0;  // Evaluation_Task: pursuer 0 obeys the behaviour tree too
+    if (slot == 0 && !scripted0) act = reinterpret_cast<const float4*>(actions)[env];
     else if (FAMILY == FAM_LEVEL4) {
       if (slot < c.n_pursuers) {  // ally: command prepared by the previous engage/observe launch (or reset)
         cmd[0] = P.lf(TE_X_CMD + 0); cmd[1] = P.lf(TE_X_CMD + 1); cmd[3] = P.lf(TE_X_CMD + 2);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
 
   // ---- set-point for this env.step
   float sp[4];
-  if (slot == 0) {  // RL agent: Quadcopter.drive (quadcopter.py:398-413)
+  if (slot == 0 && !(FAMILY == FAM_LEVEL4 && c.evaluation != 0)) {  // RL agent: Quadcopter.drive (quadcopter.py:398-413)
     command_to_velocity(act.x, act.y, act.z, act.w, sp[0], sp[1], sp[3]);
     sp[2] = 0.0f;
   } else {
@@ -398,8 +399,9 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
 #pragma unroll
         for (int k = 0; k < 3; ++k) p.dstate[((size_t)(TE_X_REF + k) * p.D + s) * p.Npad + env0 + l] = sm[(r.obs_pos() + k * p.D + s) * kEPB + l];
       }
-      for (int it = threadIdx.x - 192; it < kEPB * (r.P - 1); it += 64) {
-        const int l = it & (kEPB - 1), s = 1 + it / kEPB;
+      const int first = p.cfg.evaluation ? 0 : 1;  // Evaluation_Task scripts pursuer 0 as well
+      for (int it = threadIdx.x - 192; it < kEPB * (r.P - first); it += 64) {
+        const int l = it & (kEPB - 1), s = first + it / kEPB;
         if (l >= nvalid) continue;
         SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + l, r.P}, sm, l, r, p.D, r.P, env0 + l, sm[r.prevalid() * kEPB + l] != 0u};
         prepare_slot(p.cfg, v, s);
@@ -636,7 +638,9 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->n_envs < 1) return fail("te_create: n_envs < 1");
   if (cfg->n_pursuers < 1 || cfg->n_invaders < 1 || D > kMaxD) return fail("te_create: need 1 <= P, 1 <= I, P + I <= 32");
   if (cfg->substeps < 1 || cfg->substeps > 255) return fail("te_create: substeps out of range");
-  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_EXP05) return fail("te_create: unknown task");
+  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_EVALUATION) return fail("te_create: unknown task");
+  if (cfg->evaluation && !(family_of(cfg->task) == FAM_LEVEL4 && cfg->ally_policy == TE_ALLY_BT && !cfg->stacked_obs))
+    return fail("te_create: cfg.evaluation (Evaluation_Task rules) is the level4 task family with behaviour-tree drivers and the own-sphere observation");
   if (cfg->ally_policy == TE_ALLY_EXTERNAL && !(family_of(cfg->task) == FAM_LEVEL4 && cfg->n_pursuers == 2))
     return fail("te_create: TE_ALLY_EXTERNAL (exp05) is the level4 task family with exactly 2 pursuers (exp05_vFinal_task.py:103)");
   if (cfg->stacked_obs && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: stacked_obs needs a level4-family task");
@@ -734,6 +738,26 @@ __attribute__((visibility("default"))) int te_reset(te_env* e, const uint8_t* en
     hipLaunchKernelGGL((reset_kernel<decltype(fam)::value>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, e->p, env_mask);
   });
   launch_census(e, (hipStream_t)stream);
+  TE_HIP(hipGetLastError());
+  return 0;
+}
+
+// Evaluation_Task.compute_info (evaluation_task.py:553-574): (lw_kills, lw_alive, lw_munitions, current_wave, step) per pursuer
+__global__ __launch_bounds__(256) void wingman_info_kernel(Params p, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x, P = p.cfg.n_pursuers;
+  if (i >= p.N * P) return;
+  const int env = i / P, s = i - env * P;
+  const GView v{p.dstate, p.estate, p.D, p.Npad, env, P};
+  int32_t* row = out + (size_t)i * 5;
+  row[0] = v.gi(TE_D_KILLS, s); row[1] = v.gi(TE_D_ARMED, s) ? 1 : 0; row[2] = v.gi(TE_D_MUNITION, s);
+  row[3] = v.egi(TE_E_ROUND); row[4] = v.egi(TE_E_STEP);
+}
+__attribute__((visibility("default"))) int te_wingman_info(te_env* e, int32_t* wingman_info, void* stream) {
+  if (!e || !wingman_info) return fail("te_wingman_info: null argument");
+  if (!e->p.cfg.evaluation) return fail("te_wingman_info: per-wingman kills are only counted under cfg.evaluation (Evaluation_Task)");
+  DeviceGuard guard(e->device);
+  const int n = e->p.N * e->p.cfg.n_pursuers;
+  hipLaunchKernelGGL(wingman_info_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->p, wingman_info);
   TE_HIP(hipGetLastError());
   return 0;
 }

@@ -284,11 +284,12 @@ template <class V> TE_DEV int kamikaze_update(const te_config& c, const V& v, ui
 // planes by the engage/observe kernel, where the pursuer-invader distances are at hand in LDS
 template <class V> TE_DEV void prepare_slot(const te_config& c, const V& v, int s) {
   const int Pn = c.n_pursuers;
-  if (s == 0 || s >= Pn || !v.gi(TE_D_ARMED, s)) return;
+  // Evaluation_Task.drive_lw (evaluation_task.py:257-275) flies EVERY armed pursuer, pursuer 0 included
+  if ((s == 0 && !c.evaluation) || s >= Pn || !v.gi(TE_D_ARMED, s)) return;
   const uint32_t S = (uint32_t)v.egi(TE_E_SNAP_MASK);
   // drive_loyalwingmen: get_armed_pursuers()[1:] (exp03_vFinal_task.py:238-244): with the agent dead the
   // first armed ally is the one that is skipped
-  if (!v.gi(TE_D_ARMED, 0)) {
+  if (!c.evaluation && !v.gi(TE_D_ARMED, 0)) {
     int first = -1;
     for (int a = 1; a < Pn; ++a) if (v.gi(TE_D_ARMED, a)) { first = a; break; }
     if (s == first) return;
@@ -317,7 +318,7 @@ template <class V> TE_DEV void publish_pursuer_ref(const V& v, int s) {
 }
 template <class V> TE_DEV void prepare_level4_commands(const te_config& c, const V& v) {
   for (int s = 0; s < c.n_pursuers; ++s) publish_pursuer_ref(v, s);
-  for (int s = 1; s < c.n_pursuers; ++s) prepare_slot(c, v, s);
+  for (int s = c.evaluation ? 0 : 1; s < c.n_pursuers; ++s) prepare_slot(c, v, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,7 +348,8 @@ template <class V> TE_DEV void level4_spawn_slot(const te_config& c, const V& v,
       for (int k = 0; k < 4; ++k) v.sf(TE_D_ALLY_ACTION + k, s, 0.0f);
     }
   }
-  v.si(TE_D_NAV_STATE, s, TE_NAV_WAIT);
+  // navigators reset(); a pursuer's word counts its kills of the episode under cfg.evaluation and survives the waves
+  if (s >= Pn || reset) v.si(TE_D_NAV_STATE, s, TE_NAV_WAIT);
 }
 // armed mask once every slot has been through level4_spawn_slot
 template <class V> TE_DEV uint32_t level4_mask_after_spawn(const te_config& c, const V& v, int round, bool reset) {
@@ -728,6 +730,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
     if (u01(r.x) < c.hit_prob) {  // gun.py:94; entities_manager.shoot_by_ids (:238-248)
       kill(tgt);
       if (p == 0) agent_shots += 1; else ally_shots += 1;
+      if (c.evaluation) v.si(TE_D_KILLS, p, v.gi(TE_D_KILLS, p) + 1);  // lw_kills (evaluation_task.py:498-499)
     }
   }
   TE_LSTAMP(8);
@@ -748,14 +751,15 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
   const int allies_kills = v.egi(TE_E_ALLIES_KILLS) + ally_shots;
   const int deads = v.egi(TE_E_DEADS) + exploded;
   v.esi(TE_E_AGENT_KILLS, agent_kills); v.esi(TE_E_ALLIES_KILLS, allies_kills); v.esi(TE_E_DEADS, deads);
-  // process_invaders_in_origin (:656-659)
-  for (uint32_t m = org & inv_bits; m; m &= m - 1) kill(__ffs(m) - 1);
+  // process_invaders_in_origin (:656-659); commented out in Evaluation_Task.on_step_middle (evaluation_task.py:397)
+  if (!c.evaluation)
+    for (uint32_t m = org & inv_bits; m; m &= m - 1) kill(__ffs(m) - 1);
 
   TE_LSTAMP(9);
   // compute_reward (:423-515)
-  float reward;
+  float reward = 0.0f;  // Evaluation_Task.compute_reward returns 0 (evaluation_task.py:508-515)
   const V3 apos = obs_pos(v, 0);
-  {
+  if (!c.evaluation) {
     float g[3];
     gun_state(c, v.gi(TE_D_MUNITION, 0), v.gi(TE_D_LAST_FIRED, 0), step, max_munition_of(c, 0), g);
     const float dist_origin = norm(apos);
@@ -789,9 +793,14 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
   const int armed_invaders = __popc(A & inv_bits), armed_pursuers = __popc(A & pur_bits);
   const int round = v.egi(TE_E_ROUND);
   const bool all_rounds_over = armed_invaders == 0 && round >= c.n_rounds;
-  bool term = step > max_step || all_rounds_over;
-  if (!term) {
-    if (zone || armed_pursuers == 0 || !(A & 1u) || apos.z < -5.99f) term = true;
+  bool term;
+  if (c.evaluation) {  // evaluation_task.py:519-551: optional time limit, all rounds over, anybody outside, nobody left
+    term = (c.max_step > 0 && step > max_step) || all_rounds_over || zone != 0u || armed_pursuers == 0;
+  } else {
+    term = step > max_step || all_rounds_over;
+    if (!term) {
+      if (zone || armed_pursuers == 0 || !(A & 1u) || apos.z < -5.99f) term = true;
+    }
   }
   TE_LSTAMP(11);
   // info (:571-578)

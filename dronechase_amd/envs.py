@@ -92,6 +92,41 @@ class Exp05vFinalEnvironment(_SingleEnv):  # level4/exp05_vFinal_environment.py
         return super().step(rl_action)
 
 
+class EvaluationEnvironment(_SingleEnv):  # level4/evaluation_environment.py (behaviour-tree drivers)
+    """`EvaluationEnvironment(configuration, GUI, rl_frequency)`: every wingman is flown by the task
+    (evaluation_environment.py:170-187); `configuration["drivers"]` is the reference's list of
+    `{"type": "bt", "name": ...}` (evaluation_exp01_1bt_app_ready.py:64-68).  Drivers of type "nn" need a
+    stable-baselines3 checkpoint (`PPO.load`, evaluation_task.py:658-661) and are refused here; a policy object can fly
+    the ally through Exp05vFinalEnvironment instead.  `step` returns reward 0 and the per-wingman info rows
+    `{name: {"lw_kills", "lw_alive", "lw_munitions", "current_wave", "step"}}` of the armed wingmen (:553-574)."""
+    TASK = "evaluation"
+    INFO_KEYS = ("lw_kills", "lw_alive", "lw_munitions", "current_wave", "step")
+
+    def __init__(self, configuration: Optional[dict] = None, GUI: bool = False, rl_frequency: int = 15, dome_radius: Optional[float] = None,
+                 **overrides):
+        configuration = dict(configuration or {})
+        drivers = configuration.get("drivers", [{"type": "bt", "name": "bt_1"}])
+        if any(d.get("type") != "bt" for d in drivers):
+            raise ValueError("EvaluationEnvironment: only behaviour-tree drivers ({'type': 'bt'}) are built; 'nn' drivers load an SB3 checkpoint")
+        self.driver_names = [d.get("name", f"bt_{i + 1}") for i, d in enumerate(drivers)]
+        from . import _lib
+        P, mun = len(drivers), int(configuration.get("munition_per_defender", 20))
+        rounds = int(_lib.load().te_calculate_rounds(P, mun))  # evaluation_task.py:96-100
+        limited = bool(configuration.get("TIME_IS_LIMITED", False))
+        overrides.update(n_pursuers=P, munition=mun, n_rounds=rounds, n_invaders=rounds,
+                         born_radius=float(configuration.get("ENEMY_BORN_RADIUS", 6)),
+                         step_increment=int(configuration.get("STEP_INCREMENT", 100)),
+                         max_step=int(configuration.get("MAX_STEP", 300)) if limited else 0)
+        super().__init__(dome_radius, rl_frequency, GUI, **overrides)
+
+    def step(self, actions_not_used=None):
+        obs, reward, done, truncated, _ = super().step(np.zeros(4, np.float32))
+        rows = self._b.wingman_info()[0].cpu().numpy()
+        info = {name: dict(zip(self.INFO_KEYS, (int(rows[p, 0]), bool(rows[p, 1]), *(int(x) for x in rows[p, 2:]))))
+                for p, name in enumerate(self.driver_names) if rows[p, 1]}
+        return obs, reward, done, truncated, info
+
+
 class PyflytL2EnviromentModifiedV2(_SingleEnv):  # level2/pyflyt_level2_environment_modified_v2.py:15 (sic)
     TASK = "stage01"
     DEFAULT_DOME = 10.0
@@ -106,5 +141,5 @@ class Level5Environment(_SingleEnv):  # threatsense/level5/level5_envrionment.py
     TASK = "level5"
 
 
-ENV_TASKS = {cls: cls.TASK for cls in (Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment,
+ENV_TASKS = {cls: cls.TASK for cls in (Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment, EvaluationEnvironment,
                                        PyflytL2EnviromentModifiedV2, PyflytL3EnviromentV2, Level5Environment)}

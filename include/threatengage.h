@@ -42,8 +42,11 @@ enum {
   TE_TASK_EXP04 = 5,   /* level4/exp04_vFinal_environment.py (ally frozen, x10 approach bonus) */
   TE_TASK_LEVEL5 = 6,  /* threatsense/level5/level5_envrionment.py + tasks/level5_task.py: the exp03 task with 6 pursuers,
                           12 invaders and the FusedLIDAR stacked-sphere observation (te_step_stacked) */
-  TE_TASK_EXP05 = 7    /* level4/exp05_vFinal_environment.py + tasks/exp05_vFinal_task.py: exp03 with the ally driven by a
+  TE_TASK_EXP05 = 7,   /* level4/exp05_vFinal_environment.py + tasks/exp05_vFinal_task.py: exp03 with the ally driven by a
                           second policy (drive_lw_rl_agent, :252-260): te_observe_ally / te_set_ally_actions */
+  TE_TASK_EVALUATION = 8 /* level4/evaluation_environment.py + tasks/evaluation_task.py with behaviour-tree drivers only
+                          (apps/threatengage_runner/stage03/experiments/01/evaluation_exp01_1bt_app_ready.py): cfg.evaluation = 1,
+                          n_pursuers = number of drivers (default 1) */
 };
 
 /* ally (pursuer slots >= 1) policy: nobody (the set-point persists), LoyalWingmanBehaviorTree, drive([0,0,0,1]) every
@@ -145,7 +148,12 @@ typedef struct te_config {
   int32_t kamikaze_cone_check; /* 0: air-combat-only navigator (_is_building_path_clear == False, used by every
                                   vFinal task); 1: cone test of loitering_munition_navigator.py:78-87 */
   int32_t stacked_obs;    /* 1: keep the per-wingman snapshot ring and serve te_step_stacked (level5) */
-  int32_t reserved[4];
+  int32_t evaluation;     /* 1: Evaluation_Task rules (tasks/evaluation_task.py): EVERY pursuer is flown by the behaviour tree
+                             (drivers of type "bt", :257-275,655-668; te_step's actions are ignored), reward 0 (:508-515), no
+                             invaders-in-origin rule (:397), termination = time limit only if max_step > 0 (TIME_IS_LIMITED,
+                             :519-524), all rounds over, anybody outside the dome, all pursuers destroyed (:526-551); kills are
+                             counted per wingman (TE_D_KILLS) for te_wingman_info */
+  int32_t reserved[3];
 
   te_quad_params quad;
 } te_config;
@@ -180,7 +188,9 @@ enum {
   TE_D_ARMED = 54,     /* i32 */
   TE_D_MUNITION = 55,  /* i32 */
   TE_D_LAST_FIRED = 56,/* i32 */
-  TE_D_NAV_STATE = 57, /* i32 TE_NAV_* */
+  TE_D_NAV_STATE = 57, /* i32 TE_NAV_* (invaders) */
+  TE_D_KILLS = 57,     /* i32 the same word of a PURSUER under cfg.evaluation: Evaluation_Task.lw_kills of this episode
+                             (evaluation_task.py:498-499); 0 otherwise */
   TE_DRONE_WORDS = 58
 };
 enum {
@@ -206,6 +216,10 @@ typedef struct te_env te_env; /* opaque */
  * Mirrors Task.init_constants (exp03_vFinal_task.py:88-112, level3/components/stages.py:65-83,
  * level2/pyflyt_level2_environment_modified_v2.py:27-47). */
 int te_config_default(te_config* cfg, int32_t task);
+
+/* Task.calculate_rounds (exp03_vFinal_task.py:198-226): the number of waves (= invader slots) `defenders` pursuers with
+ * `munition` rounds each can clear; what te_config_default puts into n_rounds / n_invaders. */
+int te_calculate_rounds(int32_t defenders, int32_t munition);
 
 /* Replaces N x `Env.__init__` (exp03_vFinal_environment.py:42-63): allocates HBM state for
  * cfg->n_envs environments on `device_id` and runs on_env_init + on_episode_start. */
@@ -257,6 +271,13 @@ int te_observe_stacked(te_env* env, float* obs_stacked, uint8_t* obs_mask, float
 int te_observe_ally(te_env* env, float* ally_lidar, float* ally_inertial, float* ally_last_action, uint8_t* ally_active,
                     void* stream);
 int te_set_ally_actions(te_env* env, const float* ally_actions, void* stream);
+
+/* Evaluation_Task.compute_info (evaluation_task.py:553-574), cfg.evaluation only: wingman_info [N,P,5] i32 with the rows
+ * (lw_kills, lw_alive, lw_munitions, current_wave, step) of every pursuer AFTER the last te_step (the reference lists the
+ * armed pursuers only: a row with lw_alive == 0 is one it would omit).  For envs that auto-reset in that step the rows
+ * describe the fresh episode; callers that want an episode's final rows read them with cfg.auto_reset = 0, as the
+ * reference's evaluation loop does (evaluation_exp01_1bt_app_ready.py:80-96). */
+int te_wingman_info(te_env* env, int32_t* wingman_info, void* stream);
 
 /* Synthetic random-action generator of the throughput harness
  * (apps/threatengage_runner/interactive/analyse.py:55-59): dir ~ U(-1,1)^3, mag ~ U(0,1),

@@ -1015,10 +1015,11 @@ static void level4_setup_round(ote_env* E, int e, int round) {
   }
 }
 /* OffsetHandler.on_episode_start + navigators reset (exp03_vFinal_task.py:173-175,265-268) */
-static void level4_refresh_snapshot(ote_env* E, int e) {
+static void level4_refresh_snapshot(ote_env* E, int e, int reset) {
   ote_drone* dr = &E->drones[(size_t)e * E->D];
   E->envs[e].snap_mask = armed_mask(dr, E->D);
-  for (int i = 0; i < E->D; ++i) dr[i].nav_state = TE_NAV_WAIT;
+  /* a pursuer's word is its kill counter under cfg.evaluation (TE_D_KILLS): cleared with the episode, not with the wave */
+  for (int i = reset ? 0 : E->cfg.n_pursuers; i < E->D; ++i) dr[i].nav_state = TE_NAV_WAIT;
 }
 /* Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146, exp03_vFinal_task.py:255-274) */
 static void level4_reset_env(ote_env* E, int e) {
@@ -1044,7 +1045,7 @@ static void level4_reset_env(ote_env* E, int e) {
     level4_position(c, (real)c->pursuer_spawn_radius, u01(r[0]), u01(r[1]), pos);
     replace_drone(&dr[p], pos);
   }
-  level4_refresh_snapshot(E, e);
+  level4_refresh_snapshot(E, e, 1);
 }
 
 static void note_margin(real* m, real value, real threshold) {
@@ -1070,11 +1071,13 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   /* (1) agent command (quadcopter.py:398-413) */
   real cmd[4] = {(real)action[0], (real)action[1], (real)action[2], (real)action[3]};
   for (int k = 0; k < 4; ++k) er->last_action[k] = cmd[k];
-  command_to_setpoint(cmd, dr[0].setpoint);
+  if (!c->evaluation) command_to_setpoint(cmd, dr[0].setpoint); /* EvaluationEnvironment.step(actions_not_used) (evaluation_environment.py:170-187) */
 
   /* (2) task.on_step_start (exp03_vFinal_task.py:232-244,276-283) on the CURRENT offsets snapshot */
   for (int j = P; j < D; ++j) if (dr[j].armed) kamikaze_update(c, dr, er->snap_mask, j);
-  if (dr[0].armed) {
+  if (c->evaluation) { /* Evaluation_Task.drive_lw (evaluation_task.py:257-275): every armed pursuer, drivers of type "bt" */
+    for (int p = 0; p < P; ++p) if (dr[p].armed) wingman_update(c, dr, er->snap_mask, p, er->step);
+  } else if (dr[0].armed) {
     /* get_armed_pursuers()[1:] : with the agent armed these are the armed allies */
     for (int p = 1; p < P; ++p) {
       if (!dr[p].armed) continue;
@@ -1116,6 +1119,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
     if (gun_shoot(c, &dr[p], step, u01(r[0]))) { /* entities_manager.shoot_by_ids (:238-248) */
       disarm(&dr[tgt]);
       if (p == 0) agent_shots += 1; else ally_shots += 1;
+      if (c->evaluation) dr[p].nav_state += 1; /* lw_kills (evaluation_task.py:498-499), kept in the pursuer's TE_D_KILLS word */
     }
   }
   /* process_explosion_range_invaders (:359-390), same (stale) distance matrix */
@@ -1136,8 +1140,8 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
     else exploded += 1;
   }
   er->agent_kills += agent_shots; er->allies_kills += ally_shots; er->deads += exploded;
-  /* process_invaders_in_origin (:656-659; offsets_handler.py:341-348) */
-  for (int j = P; j < D; ++j) {
+  /* process_invaders_in_origin (:656-659; offsets_handler.py:341-348); commented out in Evaluation_Task (evaluation_task.py:397) */
+  for (int j = P; j < D && !c->evaluation; ++j) {
     if (!((S >> j) & 1u)) continue;
     real n = norm3(dr[j].obs_pos);
     note_state_margin(mg, n, (real)c->origin_range);
@@ -1146,7 +1150,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
 
   /* compute_reward (:423-515) */
   real score = 0, bonus = 0, penalty = 0;
-  {
+  if (!c->evaluation) { /* Evaluation_Task.compute_reward is 0 (evaluation_task.py:508-515) */
     const ote_drone* ag = &dr[0];
     real g[3];
     gun_state(c, ag, step, max_munition_of(c, 0), g);
@@ -1187,7 +1191,16 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   for (int p = 0; p < P; ++p) armed_pursuers += dr[p].armed;
   int all_rounds_over = (armed_invaders == 0) && (er->round >= c->n_rounds);
   int term = 0;
-  if (step > er->max_step) term = 1;
+  if (c->evaluation) { /* evaluation_task.py:519-551 */
+    if (c->max_step > 0 && step > er->max_step) term = 1; /* TIME_IS_LIMITED */
+    if (all_rounds_over || armed_pursuers == 0) term = 1;
+    for (int i = 0; i < D; ++i)
+      if ((S >> i) & 1u) {
+        real n = norm3(dr[i].obs_pos);
+        note_state_margin(mg, n, (real)c->dome_radius);
+        if (n > (real)c->dome_radius) term = 1;
+      }
+  } else if (step > er->max_step) term = 1;
   else if (all_rounds_over) term = 1;
   else {
     for (int i = 0; i < D; ++i)
@@ -1227,7 +1240,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   if (!term && !all_rounds_over && armed_invaders == 0 && armed_pursuers > 0) {
     er->round += (er->round < c->n_rounds) ? 1 : c->n_rounds; /* advance_round (:155-175) */
     level4_setup_round(E, e, er->round);
-    level4_refresh_snapshot(E, e);
+    level4_refresh_snapshot(E, e, 0);
   }
 
   /* (8) VecEnv auto-reset */
@@ -1600,6 +1613,18 @@ OTE_API int ote_set_ally_actions(ote_env* E, const float* actions) {
     for (int k = 0; k < 4; ++k) { cmd[k] = (real)actions[(size_t)e * 4 + k]; E->envs[e].ally_action[k] = cmd[k]; }
     command_to_setpoint(cmd, dr[1].setpoint);
   }
+  return 0;
+}
+/* Evaluation_Task.compute_info (evaluation_task.py:553-574): (lw_kills, lw_alive, lw_munitions, current_wave, step) per pursuer */
+OTE_API int ote_wingman_info(const ote_env* E, int32_t* out) {
+  const te_config* c = &E->cfg;
+  if (!c->evaluation) return 1;
+  for (int e = 0; e < c->n_envs; ++e)
+    for (int p = 0; p < c->n_pursuers; ++p) {
+      const ote_drone* d = &E->drones[(size_t)e * E->D + p];
+      int32_t* row = out + ((size_t)e * c->n_pursuers + p) * 5;
+      row[0] = d->nav_state; row[1] = d->armed ? 1 : 0; row[2] = d->munition; row[3] = E->envs[e].round; row[4] = E->envs[e].step;
+    }
   return 0;
 }
 OTE_API int ote_step(ote_env* E, const float* actions, float* lidar, float* inertial, float* last_action, float* reward,

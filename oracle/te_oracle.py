@@ -46,6 +46,7 @@ def lib(precision: str = "f64") -> C.CDLL:
         L.ote_observe_stacked.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.ote_observe_ally.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.ote_set_ally_actions.argtypes = [C.c_void_p, C.c_void_p]
+        L.ote_wingman_info.argtypes = [C.c_void_p, C.c_void_p]
         L.ote_stack_draws.argtypes = [C.POINTER(K.Config), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
         L.ote_state_margins.argtypes = [C.c_void_p, C.c_void_p]
         L.ote_random_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
@@ -157,6 +158,13 @@ class OracleEnv:
         assert a.shape == (self.N, 4)
         rc = self.L.ote_set_ally_actions(self.h, _p(a))
         assert rc == 0, "set_ally_actions needs cfg.ally_policy == ALLY_EXTERNAL with 2 pursuers"
+
+    def wingman_info(self) -> np.ndarray:
+        """[N,P,5] i32 rows (lw_kills, lw_alive, lw_munitions, current_wave, step) (Evaluation_Task.compute_info)."""
+        out = np.empty((self.N, self.cfg.n_pursuers, 5), np.int32)
+        rc = self.L.ote_wingman_info(self.h, _p(out))
+        assert rc == 0, "wingman_info needs cfg.evaluation"
+        return out
 
     def stack_margins(self) -> np.ndarray:
         """Smallest angular distance (rad) of any feature binned during the last step to a LIDAR cell boundary."""
