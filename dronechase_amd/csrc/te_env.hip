@@ -440,49 +440,71 @@ __global__ __launch_bounds__(256) void fill_ones_kernel(float* __restrict__ dst,
   for (size_t i = (quads << 2) + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_floats; i += stride) dst[i] = 1.0f;
 }
 
-// exp05: Exp05_vFinal_Task.compute_lw_observation (exp05_vFinal_task.py:265-292) of pursuer `me` = 1.  One thread per env,
-// straight from the state planes (coalesced over envs); the sphere's background was streamed by fill_ones_kernel on the
-// same stream, only the owner cells are patched here.  Same rules as the agent's sphere: every OTHER armed drone at its
-// last IMU position, seen from the ally's IMU attitude, closer wins in slot order, empty right after a reset.
+// exp05: Exp05_vFinal_Task.compute_lw_observation (exp05_vFinal_task.py:265-292) of pursuer `me` = 1.  One workgroup per
+// chunk of 64 envs, straight from the state planes (coalesced over envs): (env, drone) items compute the LIDAR cell and
+// range of every other armed drone seen from the ally's IMU attitude into LDS, all threads stream the chunk's tile
+// (ones), then the owner of each cell is patched in.  Same rules as the agent's sphere: closer wins in slot order, empty
+// right after a reset.
 __global__ __launch_bounds__(256) void observe_ally_kernel(Params p, float* __restrict__ lidar, float* __restrict__ inertial,
                                                            float* __restrict__ last_action, uint8_t* __restrict__ active) {
-  const int env = blockIdx.x * 256 + threadIdx.x;
-  if (env >= p.N) return;
+  __shared__ uint32_t s_cell[kMaxD * kEPB];
+  __shared__ float s_rhat[kMaxD * kEPB];
   const te_config& c = p.cfg;
   const int me = 1, D = p.D;
-  const GView v{p.dstate, p.estate, D, p.Npad, env, c.n_pursuers};
+  const int env0 = blockIdx.x * kEPB, nvalid = min(kEPB, p.N - env0);
+  const int l = threadIdx.x & (kEPB - 1), w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const bool valid = l < nvalid;
+  const GView v{p.dstate, p.estate, D, p.Npad, env0 + l, c.n_pursuers};   // planes are padded to Npad: in bounds for every lane
   const int step = v.egi(TE_E_STEP);
-  if (active) active[env] = v.gi(TE_D_ARMED, me) ? 1 : 0;
-  if (last_action)
-    reinterpret_cast<float4*>(last_action)[env] = make_float4(v.gf(TE_D_ALLY_ACTION, me), v.gf(TE_D_ALLY_ACTION + 1, me),
-                                                               v.gf(TE_D_ALLY_ACTION + 2, me), v.gf(TE_D_ALLY_ACTION + 3, me));
-  if (inertial) {
-    float in[TE_OBS_INERTIAL_WORDS];
-    inertial_obs(c, v, step, in, me);
-#pragma unroll
-    for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) inertial[(size_t)env * TE_OBS_INERTIAL_WORDS + k] = in[k];
+  const bool sees = lidar && valid && step != 0;
+  // wave roles: the last wave only streams the tile (a wave that has stores in flight waits for them before any later
+  // load returns: in-order vmcnt), the others compute the features meanwhile
+  const int nfeat = nw - 1;
+  if (sees && w < nfeat) {
+    const Q4 q = quat_of_euler(V3{v.gf(TE_D_OBS_EULER, me), v.gf(TE_D_OBS_EULER + 1, me), v.gf(TE_D_OBS_EULER + 2, me)});
+    const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    const M3 R = rotation(Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2});
+    const V3 own = obs_pos(v, me);
+    for (int j = w; j < D; j += nfeat) {
+      uint32_t cell = 0xFFFFFFFFu; float rhat = 1.0f;
+      if (j != me && v.gi(TE_D_ARMED, j)) { int cj; lidar_cell(c, mul(R, sub(obs_pos(v, j), own)), cj, rhat); cell = (uint32_t)cj; }
+      s_cell[j * kEPB + l] = cell; s_rhat[j * kEPB + l] = rhat;
+    }
   }
-  if (!lidar || step == 0) return;
-  const Q4 q = quat_of_euler(V3{v.gf(TE_D_OBS_EULER, me), v.gf(TE_D_OBS_EULER + 1, me), v.gf(TE_D_OBS_EULER + 2, me)});
-  const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-  const M3 R = rotation(Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2});
-  const V3 own = obs_pos(v, me);
-  uint32_t armed = 0;
-  for (int j = 0; j < D; ++j) armed |= (j != me && v.gi(TE_D_ARMED, j) ? 1u : 0u) << j;
+  if (lidar && w == nfeat) {  // the chunk's tile: 64 * 1014 floats, 16-byte aligned; non-temporal like the sub-step kernel's background
+    float* tile = lidar + (size_t)env0 * TE_OBS_LIDAR_WORDS;
+    const int total = nvalid * TE_OBS_LIDAR_WORDS, quads = total >> 2;
+    for (int qi = l; qi < quads; qi += kEPB) TE_FILL_STORE(reinterpret_cast<float4*>(tile) + qi);
+    for (int f = (quads << 2) + l; f < total; f += kEPB) tile[f] = 1.0f;
+  }
+  if (w == 0 && valid) {
+    const int env = env0 + l;
+    if (active) active[env] = v.gi(TE_D_ARMED, me) ? 1 : 0;
+    if (last_action)
+      reinterpret_cast<float4*>(last_action)[env] = make_float4(v.gf(TE_D_ALLY_ACTION, me), v.gf(TE_D_ALLY_ACTION + 1, me),
+                                                                 v.gf(TE_D_ALLY_ACTION + 2, me), v.gf(TE_D_ALLY_ACTION + 3, me));
+    if (inertial) {
+      float in[TE_OBS_INERTIAL_WORDS];
+      inertial_obs(c, v, step, in, me);
+#pragma unroll
+      for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) inertial[(size_t)env * TE_OBS_INERTIAL_WORDS + k] = in[k];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ones must have landed before any patch
+  __syncthreads();
+  if (!sees) return;
   // owner of a cell = smallest range, the earlier slot on ties (strict '<' in slot order, lidar_math.py:262-311); a
-  // feature clipped to 1.0 never enters an empty cell.  O(D^2) over a handful of armed drones, no per-thread arrays.
-  float* base = lidar + (size_t)env * TE_OBS_LIDAR_WORDS;
-  for (uint32_t todo = armed; todo; todo &= todo - 1) {
-    const int j = __ffs(todo) - 1;
-    int cell; float rhat;
-    lidar_cell(c, mul(R, sub(obs_pos(v, j), own)), cell, rhat);
-    if (!(rhat < 1.0f)) continue;
+  // feature clipped to 1.0 never enters an empty cell
+  float* base = lidar + (size_t)(env0 + l) * TE_OBS_LIDAR_WORDS;
+  for (int j = w; j < D; j += nw) {
+    const uint32_t cell = s_cell[j * kEPB + l];
+    const float rhat = s_rhat[j * kEPB + l];
+    if (cell == 0xFFFFFFFFu || !(rhat < 1.0f)) continue;
     bool owner = true;
-    for (uint32_t rest = armed & ~(1u << j); rest && owner; rest &= rest - 1) {
-      const int k = __ffs(rest) - 1;
-      int ck; float rk;
-      lidar_cell(c, mul(R, sub(obs_pos(v, k), own)), ck, rk);
-      if (ck == cell && (rk < rhat || (rk == rhat && k < j))) owner = false;
+    for (int k = 0; k < D; ++k) {
+      if (k == j || s_cell[k * kEPB + l] != cell) continue;
+      const float rk = s_rhat[k * kEPB + l];
+      if (rk < rhat || (rk == rhat && k < j)) owner = false;
     }
     if (!owner) continue;
     base[cell] = rhat;
@@ -770,8 +792,7 @@ __attribute__((visibility("default"))) int te_observe_ally(te_env* e, float* all
     return fail("te_observe_ally: ally_lidar and ally_last_action must be 16-byte aligned");
   DeviceGuard guard(e->device);
   hipStream_t st = (hipStream_t)stream;
-  if (ally_lidar) hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, ally_lidar, (size_t)e->p.N * TE_OBS_LIDAR_WORDS);
-  hipLaunchKernelGGL(observe_ally_kernel, dim3((e->p.N + 255) / 256), dim3(256), 0, st, e->p, ally_lidar, ally_inertial, ally_last_action, ally_active);
+  hipLaunchKernelGGL(observe_ally_kernel, dim3((e->p.N + kEPB - 1) / kEPB), dim3(256), 0, st, e->p, ally_lidar, ally_inertial, ally_last_action, ally_active);
   TE_HIP(hipGetLastError());
   return 0;
 }
