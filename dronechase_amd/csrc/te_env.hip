@@ -317,8 +317,10 @@ TE_DEV void stage_block(const Params& p, uint32_t* sm, const Rows& r, int env0) 
   }
 }
 
-template <int FAMILY>
-__global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+// THREADS = 256, or 512 when the block's LDS leaves room for only two blocks per CU (many drones per env, level5): eight
+// waves per block keep four waves per SIMD there; every loop strides by blockDim.x.
+template <int FAMILY, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void engage_observe_kernel(Params p, const float* __restrict__ actions, StepOut o) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
   const Rows r{p.D, p.cfg.n_pursuers};
   const int env0 = blockIdx.x * kEPB;
@@ -393,14 +395,15 @@ __global__ __launch_bounds__(256) void engage_observe_kernel(Params p, const flo
     // thread iteration, while waves 0..2 write the inertial / last_action rows
     if (threadIdx.x < 192) emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, 192);
     else {
-      for (int it = threadIdx.x - 192; it < kEPB * r.P; it += 64) {  // the invaders' reference of every pursuer (post-spawn)
+      const int nprep = (int)blockDim.x - 192;  // one wave of a 256-thread block, five of a 512-thread one
+      for (int it = threadIdx.x - 192; it < kEPB * r.P; it += nprep) {  // the invaders' reference of every pursuer (post-spawn)
         const int l = it & (kEPB - 1), s = it / kEPB;
         if (l >= nvalid) continue;
 #pragma unroll
         for (int k = 0; k < 3; ++k) p.dstate[((size_t)(TE_X_REF + k) * p.D + s) * p.Npad + env0 + l] = sm[(r.obs_pos() + k * p.D + s) * kEPB + l];
       }
       const int first = p.cfg.evaluation ? 0 : 1;  // Evaluation_Task scripts pursuer 0 as well
-      for (int it = threadIdx.x - 192; it < kEPB * (r.P - first); it += 64) {
+      for (int it = threadIdx.x - 192; it < kEPB * (r.P - first); it += nprep) {
         const int l = it & (kEPB - 1), s = first + it / kEPB;
         if (l >= nvalid) continue;
         SView v{GView{p.dstate, p.estate, p.D, p.Npad, env0 + l, r.P}, sm, l, r, p.D, r.P, env0 + l, sm[r.prevalid() * kEPB + l] != 0u};
@@ -609,6 +612,7 @@ struct te_env {
   int family;
   size_t lds_bytes;
   size_t stack_lds_bytes = 0;  // stacked_kernel (level5)
+  int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
   int n_fill_waves = 256;  // fill waves of the sub-step kernel (one per CU of an MI355X); TE_FILL_WAVES overrides
   // profiling (te_profile_begin / te_profile_end)
   std::vector<hipEvent_t> events;
@@ -691,6 +695,11 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
       le = hipFuncSetAttribute(reinterpret_cast<const void*>(&engage_observe_kernel<decltype(fam)::value>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
     });
+    // > 53 KB of LDS per block = at most two blocks per CU: run those with eight waves (level4 family only: D > 15)
+    e->k2_threads = (e->family == FAM_LEVEL4 && e->lds_bytes > 53 * 1024) ? 512 : 256;
+    if (const char* v = getenv("TE_K2_THREADS")) { int n = atoi(v); if ((n == 256 || n == 512) && e->family == FAM_LEVEL4) e->k2_threads = n; }
+    if (le == hipSuccess && e->k2_threads == 512)
+      le = hipFuncSetAttribute(reinterpret_cast<const void*>(&engage_observe_kernel<FAM_LEVEL4, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
     if (le == hipSuccess)
       le = hipFuncSetAttribute(reinterpret_cast<const void*>(&observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
     if (le != hipSuccess) return bail(std::string("te_create: this many drones per env needs more LDS than a workgroup may have: ") + hipGetErrorString(le));
@@ -868,11 +877,12 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   StepOut o{reward, done, info, ObsOut{stack ? nullptr : obs_lidar, obs_inertial, obs_last_action},
             ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}};
   launch_by_family(e->family, [&](auto fam) {
-    hipLaunchKernelGGL((engage_observe_kernel<decltype(fam)::value>), dim3(b2), dim3(256), e->lds_bytes, st, p, actions, o);
+    if (e->k2_threads == 512) hipLaunchKernelGGL((engage_observe_kernel<FAM_LEVEL4, 512>), dim3(b2), dim3(512), e->lds_bytes, st, p, actions, o);
+    else hipLaunchKernelGGL((engage_observe_kernel<decltype(fam)::value>), dim3(b2), dim3(256), e->lds_bytes, st, p, actions, o);
   });
   if (stack) {
     StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 1};
-    hipLaunchKernelGGL(stacked_kernel, dim3(b2), dim3(256), e->stack_lds_bytes, st, sp, *stack);
+    hipLaunchKernelGGL(stacked_kernel, dim3(b2), dim3(kStackThreads), e->stack_lds_bytes, st, sp, *stack);
   }
   if (prof) { TE_HIP(hipEventRecord(e->events[e->prof_used + 2], st)); e->prof_used += 3; }
   TE_HIP(hipGetLastError());
@@ -913,7 +923,7 @@ __attribute__((visibility("default"))) int te_observe_stacked(te_env* e, float* 
   hipLaunchKernelGGL(snapshot_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, p);
   hipLaunchKernelGGL(observe_kernel, dim3(blocks), dim3(256), e->lds_bytes, st, p, ObsOut{nullptr, obs_inertial, obs_last_action});
   StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 0};
-  hipLaunchKernelGGL(stacked_kernel, dim3(blocks), dim3(256), e->stack_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
+  hipLaunchKernelGGL(stacked_kernel, dim3(blocks), dim3(kStackThreads), e->stack_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
   TE_HIP(hipGetLastError());
   return 0;
 }

@@ -8,7 +8,7 @@
 //
 // The engage/observe kernel leaves a *snapshot* of what the observation of this step may look at (IMU positions of
 // all drones, IMU attitude of the wingmen, who is armed after the engagement, step / episode / done) in a few
-// planes BEFORE it respawns anything; stacked_kernel (one 256-thread block per 64 envs) then
+// planes BEFORE it respawns anything; stacked_kernel (one 512-thread block per 64 envs) then
 //   (1) pushes every armed wingman's entry into the ring          one (env, other drone) item per thread, per wingman
 //   (2) draws the agent's neighbourhood (Philox)                  one lane per env
 //   (3) re-projects each chosen snapshot into the agent's frame   one (env, neighbour) per thread, farther wins
@@ -129,7 +129,8 @@ struct StackParams {
   int push;              // 1: te_step_stacked (push this step's entries, clear the ring of auto-reset envs); 0: te_observe_stacked
 };
 
-__global__ __launch_bounds__(256) void stacked_kernel(StackParams p, StackOut o) {
+constexpr int kStackThreads = 512;  // 8 waves: the block's LDS (73 KB at D = 18) allows two blocks per CU, i.e. 4 waves per SIMD (+ 9 % env-steps/s over 256 threads)
+__global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, StackOut o) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
   const te_config& c = p.cfg;
   const int D = p.D, P = c.n_pursuers;
