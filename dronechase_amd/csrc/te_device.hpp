@@ -33,6 +33,8 @@ struct Derived {
   float lv_kiT[2], lv_kdT[2], av_kiT[3], av_kdT[3], zv_kiT, zv_kdT;
   float half_dt, quarter_dt2, noise_m2ln2;  // dt/2, dt^2/4, -2 ln 2 * noise_ratio^2 (Box-Muller radius incl. the noise gain)
 };
+constexpr int kMixedWaves = 2, kMixedCap = 64 * kMixedWaves;  // mixed waves per chunk; a slot that would overflow the list flies densely
+constexpr int kDenseMin = 40;                                // default of Params::dense_min: armed envs of a chunk from which a slot gets its own wave
 struct Params {
   te_config cfg;
   Derived kd;
@@ -46,6 +48,13 @@ struct Params {
   // (and by reset / set_state), read by the sub-step launch with a SCALAR load, so that a wave with nothing to fly
   // retires without a single vector memory operation
   uint32_t* slot_mask;  // [Npad / 64]
+  // Slots armed in only a few envs of a chunk do not get a wave of their own (at 4.2 armed drones per env a rollout has
+  // 7.6 armed slots per chunk, i.e. 56 % of the lanes of the flight waves would idle): their (env, slot) items share
+  // MIXED waves of 64 items.  slot_mask then holds the slots flown densely; mixed_items[chunk * kMixedCap + i] =
+  // lane | slot << 8 for i < mixed_count[chunk], written together with slot_mask.
+  int dense_min;           // kDenseMin; TE_DENSE_MIN=1 turns the mixed waves off (every armed slot flies densely)
+  uint32_t* mixed_count;   // [Npad / 64]
+  uint16_t* mixed_items;   // [Npad / 64][kMixedCap]
   // level5 (cfg.stacked_obs): observation-time snapshot planes (te_stacked.hpp SnapRows) and the snapshot ring; else null
   uint32_t* snap;
   uint32_t* ring;

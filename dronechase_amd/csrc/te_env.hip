@@ -63,35 +63,17 @@ struct NavView {
   TE_DEV float gf(int w, int s) const { return P.lf_slot(TE_X_REF + (w - TE_D_OBS_POS), s); }
 };
 
-template <int FAMILY, bool NOISE, bool FILL>
-__global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params p, const float* __restrict__ actions, FillJob fill) {
-  int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (unsigned)TE_K1_BLOCK + threadIdx.x) >> 6));
-  const int lane = threadIdx.x & 63;
+// One flight: the drone of slot `slot` of env `env` through the 16 sub-steps of this env.step.  In a DENSE wave `slot` is
+// wave-uniform and the lanes are the 64 envs of a chunk; in a MIXED wave every lane carries its own (env, slot) item of
+// the chunk's sparsely armed slots (Params::mixed_items), so `slot` is a per-lane value: the buffer addressing
+// (SlotLane: per-lane byte offset + scalar plane offset) is the same for both.
+template <int FAMILY, bool NOISE, bool MIXED>
+TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, int env, bool valid) {
   const int D = p.D;
-  const int nchunks = p.Npad >> 6;
-  float4* fill_dst = reinterpret_cast<float4*>(fill.lidar);
-  if (FILL) {
-    if (wave < (int)fill.n_fill_waves) {  // ---- fill wave
-      // grid-stride: at any moment the fill waves write one contiguous n_fill_waves KB window, which the address
-      // interleave spreads over every HBM channel
-      const uint32_t stride = fill.n_fill_waves * 64u;
-      for (uint32_t q = (uint32_t)wave * 64u + (uint32_t)lane; q < fill.total_quads; q += stride) TE_FILL_STORE(fill_dst + q);
-      return;
-    }
-    wave -= (int)fill.n_fill_waves;
-  }
-  const int slot = wave / nchunks;
-  const int chunk = wave - slot * nchunks;
-  if (slot >= D) return;
-  // Is any drone of this (slot, chunk) armed?  One wave-uniform SCALAR load: the ~8 000 idle waves of a launch used to
-  // wait for a vector flag load (and issue a background store) behind the fill waves' stores: +15 us per launch.
-  const uint32_t chunk_mask = __builtin_amdgcn_readfirstlane(((const uint32_t* __restrict__)p.slot_mask)[chunk]);
-  if (!((chunk_mask >> slot) & 1u)) return;
-  const int env = chunk * 64 + lane;  // planes are padded to Npad: lanes beyond N still read in bounds
   const SlotLane P(p.dstate, p.estate, (uint32_t)D, (uint32_t)p.Npad, (uint32_t)slot, (uint32_t)env,
                    (uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)D * (uint32_t)p.Npad, (uint32_t)TE_ENV_WORDS * (uint32_t)p.Npad);
   const int armed = P.li(TE_D_ARMED);
-  const bool active = env < p.N && armed != 0;
+  const bool active = valid && armed != 0;
   const te_config& c = p.cfg;
   const bool mode7 = (FAMILY == FAM_STAGE01) && slot == 2;
 
@@ -175,10 +157,16 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   // registers for the odd one.
   const int n_plain = c.observe_lag ? S - 1 : S;
   uint32_t na = 0, nb = 0, held_a = 0, held_b = 0;
+  // MIXED: (env, slot) ride through the loop in ONE register and are unpacked at each draw (a per-lane slot next to
+  // env would cost the kernel its 72nd VGPR, i.e. a wave per SIMD); te_create caps n_envs per te_env below 2^24
+  const uint32_t env_slot = (uint32_t)env | ((uint32_t)slot << 24);
 #define TE_DRAW(s_)                                                                   \
   if (NOISE) {                                                                        \
     if (((s_) & 1) == 0) {                                                            \
-      const U4 bits = motor_noise_bits(c, env, slot, episode, step_index, (s_));      \
+      uint32_t es_ = env_slot;                                                        \
+      if (MIXED) asm volatile("" : "+v"(es_));                                        \
+      const U4 bits = MIXED ? motor_noise_bits(c, (int)(es_ & 0xFFFFFFu), (int)(es_ >> 24), episode, step_index, (s_)) \
+                            : motor_noise_bits(c, env, slot, episode, step_index, (s_));      \
       na = bits.x; nb = bits.y; held_a = bits.z; held_b = bits.w;                     \
     } else { na = held_a; nb = held_b; }                                              \
   }
@@ -221,6 +209,51 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   }
 }
 
+template <int FAMILY, bool NOISE, bool FILL>
+__global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params p, const float* __restrict__ actions, FillJob fill) {
+  int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (unsigned)TE_K1_BLOCK + threadIdx.x) >> 6));
+  const int lane = threadIdx.x & 63;
+  const int D = p.D;
+  const int nchunks = p.Npad >> 6;
+  float4* fill_dst = reinterpret_cast<float4*>(fill.lidar);
+  if (FILL) {
+    if (wave < (int)fill.n_fill_waves) {  // ---- fill wave
+      // grid-stride: at any moment the fill waves write one contiguous n_fill_waves KB window, which the address
+      // interleave spreads over every HBM channel
+      const uint32_t stride = fill.n_fill_waves * 64u;
+      for (uint32_t q = (uint32_t)wave * 64u + (uint32_t)lane; q < fill.total_quads; q += stride) TE_FILL_STORE(fill_dst + q);
+      return;
+    }
+    wave -= (int)fill.n_fill_waves;
+  }
+  // Grid order after the fill waves: the dense candidates of the HEAD slots (agent, allies, first invader: armed in
+  // nearly every env), then the mixed-wave candidates (whole flights: started last they would also finish last; started
+  // first, their scalar look-ups delay the head flights by ~4 us), then the dense candidates of the remaining slots.
+  const int n_head = min(D, p.cfg.n_pursuers + 1) * nchunks;
+  const int n_mixed = (FAMILY == FAM_LEVEL4 && p.dense_min > 1) ? kMixedWaves * nchunks : 0;
+  if (wave >= n_head && wave < n_head + n_mixed) {  // ---- mixed wave m of a chunk: 64 (env, slot) items of its sparsely armed slots
+    wave -= n_head;
+    const int m = wave / nchunks, chunk = wave - m * nchunks;
+    const int count = __builtin_amdgcn_readfirstlane((int)((const uint32_t* __restrict__)p.mixed_count)[chunk]);
+    if (m * 64 >= count) return;
+    const int i = m * 64 + lane;
+    const bool valid = i < count;
+    const uint32_t item = valid ? (uint32_t)p.mixed_items[(size_t)chunk * kMixedCap + i] : 0u;
+    fly<FAMILY, NOISE, true>(p, actions, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid);
+    return;
+  }
+  if (wave >= n_head) wave -= n_mixed;
+  const int slot = wave / nchunks;
+  const int chunk = wave - slot * nchunks;
+  if (slot >= D) return;
+  // Does this (slot, chunk) fly as a dense wave?  One wave-uniform SCALAR load: the ~8 000 idle waves of a launch used
+  // to wait for a vector flag load (and issue a background store) behind the fill waves' stores: +15 us per launch.
+  const uint32_t chunk_mask = __builtin_amdgcn_readfirstlane(((const uint32_t* __restrict__)p.slot_mask)[chunk]);
+  if (!((chunk_mask >> slot) & 1u)) return;
+  const int env = chunk * 64 + lane;  // planes are padded to Npad: lanes beyond N still read in bounds
+  fly<FAMILY, NOISE, false>(p, actions, slot, env, env < p.N);
+}
+
 // ============================================================================================
 // K2: engagement / reward / termination / waves / auto-reset / observation
 // ============================================================================================
@@ -249,16 +282,31 @@ __global__ __launch_bounds__(256) void snapshot_kernel(Params p) {
   p.snap[(size_t)sr.episode() * p.Npad + env] = (uint32_t)v.egi(TE_E_EPISODE);
   p.snap[(size_t)sr.done() * p.Npad + env] = 0u;
 }
+// The flight plan of a chunk for the next sub-step launch, by ONE wave whose lanes are the chunk's 64 envs, slot by slot:
+// slots armed in >= kDenseMin envs (and the agent's) fly as dense waves (bit in slot_mask), the armed (env, slot) pairs of
+// the other slots go to the mixed list in slot order.  `a` = this lane's env has drone s armed (false for lanes >= nvalid).
+template <int FAMILY>
+TE_DEV void plan_slot(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint32_t& dense, int& n) {
+  const unsigned long long b = __ballot(a);
+  const int cnt = __popcll(b);
+  if (cnt == 0) return;
+  if (FAMILY != FAM_LEVEL4 || s == 0 || cnt >= dense_min || n + cnt > kMixedCap) { dense |= 1u << s; return; }
+  // rank of this lane among the armed ones: v_mbcnt counts the set bits of b below the lane
+  if (a) items[n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | (s << 8));
+  n += cnt;
+}
+TE_DEV void plan_done(const Params& p, int chunk, int lane, uint32_t dense, int n) {
+  if (lane == 0) { p.slot_mask[chunk] = dense; p.mixed_count[chunk] = (uint32_t)n; }
+}
 // rebuild slot_mask from the armed planes (after te_create / te_reset / te_set_state; during a rollout the
 // engage/observe kernel maintains it): one 64-thread block per chunk of 64 envs
+template <int FAMILY>
 __global__ __launch_bounds__(64) void census_kernel(Params p) {
   const int chunk = blockIdx.x, l = threadIdx.x, env = chunk * 64 + l;
-  uint32_t m = 0u;
-  for (int s = 0; s < p.D; ++s) {
-    const bool a = env < p.N && p.dstate[((size_t)TE_D_ARMED * p.D + s) * p.Npad + env] != 0u;
-    m |= (__ballot(a) != 0ull ? 1u : 0u) << s;
-  }
-  if (l == 0) p.slot_mask[chunk] = m;
+  uint32_t dense = 0u; int n = 0;
+  uint16_t* items = p.mixed_items + (size_t)chunk * kMixedCap;
+  for (int s = 0; s < p.D; ++s) plan_slot<FAMILY>(items, p.dense_min, l, s, env < p.N && p.dstate[((size_t)TE_D_ARMED * p.D + s) * p.Npad + env] != 0u, dense, n);
+  plan_done(p, chunk, l, dense, n);
 }
 // recompute the pending scripted commands from a freshly loaded state blob (te_set_state)
 __global__ __launch_bounds__(256) void prepare_commands_kernel(Params p) {
@@ -413,13 +461,12 @@ __global__ __launch_bounds__(THREADS) void engage_observe_kernel(Params p, const
   } else {
     emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, blockDim.x);
   }
-  if (threadIdx.x < kEPB) {  // which slots of this chunk the next sub-step launch has to fly (post-spawn flags)
-    uint32_t m = 0u;
-    for (int s = 0; s < p.D; ++s) {
-      const bool a = (int)threadIdx.x < nvalid && sm[(r.armed() + s) * kEPB + threadIdx.x] != 0u;
-      m |= (__ballot(a) != 0ull ? 1u : 0u) << s;
-    }
-    if (threadIdx.x == 0) p.slot_mask[blockIdx.x] = m;
+  if (threadIdx.x < kEPB) {  // what the next sub-step launch has to fly for this chunk (post-spawn flags)
+    uint32_t dense = 0u; int n = 0;
+    uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
+    for (int s = 0; s < p.D; ++s)
+      plan_slot<FAMILY>(items, p.dense_min, (int)threadIdx.x, s, (int)threadIdx.x < nvalid && sm[(r.armed() + s) * kEPB + threadIdx.x] != 0u, dense, n);
+    plan_done(p, (int)blockIdx.x, (int)threadIdx.x, dense, n);
   }
   TE_STAMP(p, 500, 5);
   // terminal tiles of auto-reset envs (rare, block-uniform test): ones, drained, then patched
@@ -629,10 +676,6 @@ static int fail(const std::string& m) { g_err = m; return 1; }
     if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));                  \
   } while (0)
 
-static void launch_census(te_env* e, hipStream_t st) {
-  hipLaunchKernelGGL(census_kernel, dim3(e->p.Npad / 64), dim3(64), 0, st, e->p);
-}
-
 struct DeviceGuard {
   int prev = -1; bool ok;
   explicit DeviceGuard(int dev) { ok = hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess); if (prev == dev) prev = -1; }
@@ -651,6 +694,12 @@ static int launch_by_family(int family, F&& f) {
     default: f(std::integral_constant<int, FAM_LEVEL4>{}); break;
   }
   return 0;
+}
+
+static void launch_census(te_env* e, hipStream_t st) {
+  launch_by_family(e->family, [&](auto fam) {
+    hipLaunchKernelGGL((census_kernel<decltype(fam)::value>), dim3(e->p.Npad / 64), dim3(64), 0, st, e->p);
+  });
 }
 
 extern "C" {
@@ -681,13 +730,15 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   te_env* e = new (std::nothrow) te_env();
   if (!e) return fail("te_create: out of host memory");
   e->device = device_id;
-  e->p.dstate = nullptr; e->p.estate = nullptr; e->p.slot_mask = nullptr; e->p.stage_tab = nullptr; e->p.snap = nullptr; e->p.ring = nullptr; e->p.dbg = nullptr;
+  e->p.dstate = nullptr; e->p.estate = nullptr; e->p.slot_mask = nullptr; e->p.mixed_count = nullptr; e->p.mixed_items = nullptr; e->p.stage_tab = nullptr; e->p.snap = nullptr; e->p.ring = nullptr; e->p.dbg = nullptr;
   auto bail = [&](const std::string& why) { te_destroy(e); return fail(why); };
   e->family = family_of(cfg->task);
   e->p.cfg = *cfg;
   e->p.kd = derive(*cfg);
   e->p.N = cfg->n_envs; e->p.D = D; e->p.Npad = (cfg->n_envs + 63) / 64 * 64;
   e->lds_bytes = (size_t)lds_rows(D, cfg->n_pursuers) * kEPB * sizeof(uint32_t);
+  e->p.dense_min = kDenseMin;
+  if (const char* v = getenv("TE_DENSE_MIN")) { int n = atoi(v); if (n >= 1 && n <= 65) e->p.dense_min = n; }
   if (const char* v = getenv("TE_FILL_WAVES")) { int n = atoi(v); if (n >= 1 && n <= (1 << 20)) e->n_fill_waves = n; }
   {
     hipError_t le = hipSuccess;
@@ -708,7 +759,10 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (dwords >= (1ull << 30)) return bail("te_create: n_envs * drones too large for one te_env (state planes are indexed with 32 bits); shard it");
   if (hipMalloc(&e->p.dstate, dwords * 4) != hipSuccess || hipMalloc(&e->p.estate, ewords * 4) != hipSuccess)
     return bail("te_create: hipMalloc failed");
-  if (hipMalloc(&e->p.slot_mask, (size_t)(e->p.Npad / 64) * 4) != hipSuccess) return bail("te_create: hipMalloc failed");
+  if (hipMalloc(&e->p.slot_mask, (size_t)(e->p.Npad / 64) * 4) != hipSuccess || hipMalloc(&e->p.mixed_count, (size_t)(e->p.Npad / 64) * 4) != hipSuccess ||
+      hipMalloc(&e->p.mixed_items, (size_t)(e->p.Npad / 64) * kMixedCap * sizeof(uint16_t)) != hipSuccess)
+    return bail("te_create: hipMalloc failed");
+  TE_HIP(hipMemsetAsync(e->p.mixed_count, 0, (size_t)(e->p.Npad / 64) * 4, nullptr));
   {
     const Rows r{D, cfg->n_pursuers};
     std::vector<uint32_t> tab((size_t)r.staged());
@@ -753,7 +807,7 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
   (void)hipFree(e->p.dstate);
   (void)hipFree(e->p.estate);
-  (void)hipFree(e->p.slot_mask);
+  (void)hipFree(e->p.slot_mask); (void)hipFree(e->p.mixed_count); (void)hipFree(e->p.mixed_items);
   (void)hipFree(e->p.stage_tab);
   if (e->p.snap) (void)hipFree(e->p.snap);
   if (e->p.ring) (void)hipFree(e->p.ring);
@@ -860,7 +914,7 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
       hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, obs_lidar, n_floats);
     }
   }
-  const int b1 = (int)fill.n_fill_waves + waves;
+  const int b1 = (int)fill.n_fill_waves + waves + (e->family == FAM_LEVEL4 && p.dense_min > 1 ? kMixedWaves * (p.Npad >> 6) : 0);  // + mixed-wave candidates
   launch_by_family(e->family, [&](auto fam) {
     constexpr int F = decltype(fam)::value;
     auto go = [&](auto noise_c, auto fill_c) {

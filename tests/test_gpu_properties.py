@@ -119,6 +119,45 @@ def test_observation_invariants(task, N, over):
     env.close()
 
 
+@pytest.mark.parametrize("task,N,T", [("stage03", 4096, 400), ("level5", 512, 120), ("evaluation", 2048, 300)])
+def test_mixed_waves_fly_exactly_what_dense_waves_would(task, N, T):
+    """The sub-step kernel packs the (env, slot) pairs of sparsely armed slots of a chunk into mixed waves (te_env.hip:
+    plan_slot / fly<.., MIXED>); TE_DENSE_MIN=1 (read by te_create) gives every armed slot its own wave instead.  Same
+    drones, same arithmetic: outputs and state must be bit-identical along a rollout in which sparse slots do occur."""
+    import os
+    torch = _torch()
+    from dronechase_amd import config as K, default_config
+    from dronechase_amd.batched_env import BatchedEnv
+
+    cfg = default_config(task, n_envs=N, seed=6)
+    mixed = BatchedEnv(cfg, "cuda:0")
+    old = os.environ.get("TE_DENSE_MIN")
+    os.environ["TE_DENSE_MIN"] = "1"
+    try:
+        dense = BatchedEnv(cfg, "cuda:0")
+    finally:
+        if old is None:
+            del os.environ["TE_DENSE_MIN"]
+        else:
+            os.environ["TE_DENSE_MIN"] = old
+    mixed.reset(); dense.reset()
+    D = cfg.n_drones
+    sparse_seen = 0
+    for t in range(T):
+        a = mixed.random_actions(4, t)
+        ra = (mixed.step_stacked if mixed.stacked_mode else mixed.step)(a)
+        rb = (dense.step_stacked if dense.stacked_mode else dense.step)(a)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), (task, t)
+        if t % 20 == 0:
+            w = mixed.get_state()
+            assert torch.equal(w, dense.get_state()), (task, t)
+            per_chunk = (w[: N * D * K.DRONE_WORDS].view(N // 64, 64, D, K.DRONE_WORDS)[..., K.D["ARMED"]] != 0).sum(1)
+            sparse_seen += int(((per_chunk > 0) & (per_chunk < 40)).sum())
+    assert sparse_seen > 0      # the mixed path did carry drones
+    mixed.close(); dense.close()
+
+
 def test_stage03_episode_statistics():
     """Long random-action rollout at full size: episodes end, waves advance, kills happen, and the
     terminal observation rows are only written for done envs."""
