@@ -6,14 +6,15 @@ import ctypes as C, numpy as np, torch
 from dronechase_amd import default_config
 from dronechase_amd.batched_env import BatchedEnv
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 20      # steps before the 40 sampled ones
 env = BatchedEnv(default_config("stage03", n_envs=N), "cuda:0")
 a = torch.empty((N, 4), device="cuda:0")
 env.reset()
 names = ["stage", "precompute", "logic", "barrier", "rows", "prepare", "patch"]
 acc = np.zeros(7)
-for i in range(60):
+for i in range(W + 40):
     env.random_actions(1, i, out=a); env.step(a)
-    if i >= 20:
+    if i >= W:
         out = (C.c_uint64 * 8)()
         env.L.te_debug_stamps(env._h, out, 8)
         t = np.array(list(out), dtype=np.float64)
