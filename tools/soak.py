@@ -14,6 +14,8 @@ stacked = bool(cfg.stacked_obs)
 dones = 0; rsum = 0.0; t0 = time.perf_counter()
 for t in range(steps):
     g.random_actions(11, t, out=a)
+    if int(cfg.ally_policy) == K.ALLY_EXTERNAL:  # exp05: the ally gets random commands too
+        g.observe_ally(); g.set_ally_actions(g.random_actions(12, t).clone())
     out = g.step_stacked(a) if stacked else g.step(a)
     reward, done, info = out[-3], out[-2], out[-1]
     if t % 500 == 0 or t == steps - 1:
