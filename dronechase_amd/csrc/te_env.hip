@@ -2,16 +2,20 @@
 //
 // One te_step = two launches on the caller's stream:
 //   K1 substeps_kernel       one wavefront per workgroup.  256 fill waves stream the LIDAR background (ones);
-//                            one drone wave per (slot, 64 consecutive envs), slot-major: armed lanes work out
-//                            their set-point (an invader runs its navigator here) and fly the 16 physics
-//                            sub-steps in registers (state read once, written once); a wave whose slot is
-//                            disarmed in all 64 envs retires after one load.
+//                            one DENSE drone wave per (slot, 64 consecutive envs), slot-major, for the slots armed
+//                            in most envs of the chunk, and MIXED waves of 64 (env, slot) items for its sparsely
+//                            armed slots (flight plan left by K2): armed lanes work out their set-point (an
+//                            invader runs its navigator here) and fly the 16 physics sub-steps in registers
+//                            (state read once, written once); a candidate wave with nothing to fly retires
+//                            after one scalar load.
 //   K2 engage_observe_kernel one 256-thread block per 64 envs, phases separated by barriers: stage the words the
 //                            logic reads in LDS (one round of independent coalesced loads) -> precompute
 //                            distances / masks / LIDAR cells, all threads -> wave 0, one lane per env:
 //                            engagement, reward, termination, info, hit resolution, round / reset decision ->
 //                            spawn phase, one (env, slot) per thread -> observation rows + the allies' commands
-//                            of the next step -> patch the hit cells into the background.
+//                            and the flight plan of the next step -> patch the hit cells into the background.
+// (te_step_stacked adds stacked_kernel, te_stacked.hpp; exp05 brackets te_step with te_observe_ally /
+// te_set_ally_actions.)
 // No MFMA: this is element-wise physics and byte streaming.
 //
 // Reference citations are file:line under the reference's src/ tree.
