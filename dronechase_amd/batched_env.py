@@ -75,10 +75,10 @@ class BatchedEnv:
         return actions.contiguous()
 
     # ------------------------------------------------------------------ API
-    def observe(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        _lib.check(self.L.te_observe(self._h, self._p(self.lidar), self._p(self.inertial), self._p(self.last_action),
-                                     self._stream()), "te_observe")
-        return self.lidar, self.inertial, self.last_action
+    def observe(self, out=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        lidar, inertial, last_action = self._obs_out(out)
+        _lib.check(self.L.te_observe(self._h, self._p(lidar), self._p(inertial), self._p(last_action), self._stream()), "te_observe")
+        return lidar, inertial, last_action
 
     def reset(self, mask: Optional[torch.Tensor] = None):
         if mask is not None:
@@ -88,13 +88,25 @@ class BatchedEnv:
         _lib.check(self.L.te_reset(self._h, self._p(mask), self._stream()), "te_reset")
         return self.observe()
 
-    def step(self, actions: torch.Tensor, terminal: bool = True):
+    def _obs_out(self, out):
+        """(lidar, inertial, last_action) destination tensors of this step: the internal buffers, or the caller's (e.g. slot t
+        of a rollout buffer in HBM: the observation is written where it will be kept, no copy)."""
+        if out is None:
+            return self.lidar, self.inertial, self.last_action
+        for o, ref, align in zip(out, (self.lidar, self.inertial, self.last_action), (16, 4, 16)):
+            if o.shape != ref.shape or o.dtype != ref.dtype or o.device != ref.device or not o.is_contiguous() or o.data_ptr() % align:
+                raise ValueError("out = (lidar [N,3,13,26], inertial [N,15], last_action [N,4]): contiguous float32 on the env's device, "
+                                 "lidar and last_action 16-byte aligned")
+        return tuple(out)
+
+    def step(self, actions: torch.Tensor, terminal: bool = True, out=None):
         a = self._check_actions(actions)
         t = (self.t_lidar, self.t_inertial, self.t_last_action) if terminal else (None, None, None)
-        _lib.check(self.L.te_step(self._h, self._p(a), self._p(self.lidar), self._p(self.inertial),
-                                  self._p(self.last_action), self._p(self.reward), self._p(self.done), self._p(self.info),
+        lidar, inertial, last_action = self._obs_out(out)
+        _lib.check(self.L.te_step(self._h, self._p(a), self._p(lidar), self._p(inertial),
+                                  self._p(last_action), self._p(self.reward), self._p(self.done), self._p(self.info),
                                   self._p(t[0]), self._p(t[1]), self._p(t[2]), self._stream()), "te_step")
-        return self.lidar, self.inertial, self.last_action, self.reward, self.done, self.info
+        return lidar, inertial, last_action, self.reward, self.done, self.info
 
     # level5 ---------------------------------------------------------------------------------
     def observe_stacked(self):

@@ -57,7 +57,8 @@ class LidarInertialActionPolicy(nn.Module):
 
     def dist(self, obs):
         mu, v = self(obs)
-        return torch.distributions.Normal(mu, self.log_std.exp().expand_as(mu)), v
+        # validate_args=False: the argument check is a host synchronisation per call (and cannot be captured in a graph)
+        return torch.distributions.Normal(mu, self.log_std.exp().expand_as(mu), validate_args=False), v
 
 
 class PolicyDriver:
@@ -91,6 +92,7 @@ class PPOConfig:
     ent_coef: float = 0.0
     max_grad_norm: float = 0.5
     learning_rate: float = 3e-4
+    use_graph: bool = True       # collect(): policy forward + sampling + te_step captured once in a HIP graph and replayed per step
     reward_scale: float = 1e-3   # rewards reach +-1000 (exp03_vFinal_task.py:423-515); SB3 users wrap VecNormalize
 
 
@@ -144,30 +146,109 @@ class PPO:
         if self.distributed:  # same initial weights on every rank
             for p in self.policy.parameters():
                 torch.distributed.broadcast(p.data, src=0)
-        lidar, inertial, last_action = env.reset()
-        self._obs = {"lidar": lidar, "inertial_data": inertial, "last_action": last_action}
+        env.reset()
+        self.direct = env.N % 2 == 0   # slot t of the LIDAR buffer starts on a 16-byte boundary (4 056 bytes per env)
+        self._obs = None               # set by the first collect(): te_observe of the reset state
         self.num_timesteps = 0
 
-    def _current_obs(self):
-        return self._obs
+    def _slot(self, t: int):
+        b = self.buf
+        return b.obs["lidar"][t], b.obs["inertial_data"][t], b.obs["last_action"][t]
+
+    # ------------------------------------------------------------------ graph-captured rollout step
+    def _capture_step(self) -> None:
+        """One rollout step = ~40 small PyTorch launches (policy forward, sampling, clamps) + the two env kernels; at
+        16 384 envs that is launch-bound in eager mode (1.9 ms per step, of which the kernels need ~0.8).  The step is
+        captured once in a HIP graph on static tensors and replayed: te_step enqueues on PyTorch's current stream, so
+        its launches are captured like any other."""
+        b = self.buf
+        self._g_obs = {k: torch.empty_like(v[0]) for k, v in b.obs.items()}
+        self._g = dict(a=torch.empty_like(b.actions[0]), logp=torch.empty_like(b.logp[0]), v=torch.empty_like(b.values[0]),
+                       reward=torch.empty_like(b.rewards[0]), done=torch.empty_like(b.dones[0]))
+        for k in self._g_obs:
+            self._g_obs[k].copy_(self._obs[k])
+
+        def step_once():
+            # the diagonal Gaussian by hand: torch.normal on expanded tensors checks its arguments on the host, which
+            # a capturing stream does not permit.  log N(a; mu, sigma) = -(a - mu)^2 / (2 sigma^2) - log sigma - log sqrt(2 pi)
+            mu, v = self.policy(self._g_obs)
+            log_std = self.policy.log_std
+            eps = torch.randn_like(mu)
+            a = mu + log_std.exp() * eps
+            logp = (-0.5 * eps * eps - log_std - 0.9189385332046727).sum(-1)
+            self._g["a"].copy_(a); self._g["logp"].copy_(logp); self._g["v"].copy_(v)
+            lidar, inertial, last_action, reward, done, _ = self.env.step(torch.max(torch.min(a, self.high), self.low).contiguous(), terminal=False)
+            self._g["reward"].copy_(reward); self._g["done"].copy_(done)
+            self._g_obs["lidar"].copy_(lidar); self._g_obs["inertial_data"].copy_(inertial); self._g_obs["last_action"].copy_(last_action)
+
+        state = self.env.get_state().clone()          # warm-up and capture must not advance the environments
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step_once()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            step_once()
+        self.env.set_state(state)
+        for k in self._g_obs:
+            self._g_obs[k].copy_(self._obs[k])
+
+    @torch.no_grad()
+    def _collect_graph(self) -> Dict[str, float]:
+        b, c = self.buf, self.cfg
+        if self._obs is None:
+            self._obs = dict(zip(("lidar", "inertial_data", "last_action"), self.env.observe()))
+        if not hasattr(self, "_graph"):
+            self._capture_step()
+        ep_rew = torch.zeros((), device=self.device); ep_n = torch.zeros((), dtype=torch.int64, device=self.device)
+        for t in range(c.n_steps):
+            for k in b.obs:
+                b.obs[k][t].copy_(self._g_obs[k])
+            self._graph.replay()
+            b.actions[t].copy_(self._g["a"]); b.logp[t].copy_(self._g["logp"]); b.values[t].copy_(self._g["v"])
+            torch.mul(self._g["reward"], c.reward_scale, out=b.rewards[t]); b.dones[t].copy_(self._g["done"])
+            ep_rew += self._g["reward"].mean(); ep_n += self._g["done"].sum().long()
+        self._obs = self._g_obs
+        _, last_v = self.policy(self._obs)
+        b.finish(last_v, c.gamma, c.gae_lambda)
+        self.num_timesteps += c.n_steps * self.env.N
+        return {"mean_step_reward": float(ep_rew) / c.n_steps, "episodes_finished": int(ep_n)}
 
     @torch.no_grad()
     def collect(self) -> Dict[str, float]:
+        if self.cfg.use_graph and self.device.type == "cuda":
+            return self._collect_graph()
+        return self._collect_eager()
+
+    @torch.no_grad()
+    def _collect_eager(self) -> Dict[str, float]:
+        """The environment writes the observation of step t+1 straight into slot t+1 of the rollout buffer (te_step takes
+        the destination pointers): no per-step copy of the 4 KB/env observation, and no host synchronisation inside the
+        loop.  The observation after the last step goes to the env's own buffers and seeds slot 0 of the next rollout."""
         b, c = self.buf, self.cfg
-        ep_rew, ep_n = 0.0, 0
+        ep_rew = torch.zeros((), device=self.device); ep_n = torch.zeros((), dtype=torch.int64, device=self.device)
+        if self._obs is None:
+            self._obs = dict(zip(("lidar", "inertial_data", "last_action"), self.env.observe()))
+        for k in b.obs:
+            b.obs[k][0].copy_(self._obs[k])
         for t in range(c.n_steps):
-            obs = self._current_obs()
-            for k in b.obs:
-                b.obs[k][t].copy_(obs[k])
-            dist, v = self.policy.dist(obs)
+            dist, v = self.policy.dist({k: o[t] for k, o in b.obs.items()})
             a = dist.sample()
             b.actions[t], b.logp[t], b.values[t] = a, dist.log_prob(a).sum(-1), v
-            lidar, inertial, last_action, reward, done, _info = self.env.step(torch.max(torch.min(a, self.high), self.low).contiguous(), terminal=False)
+            dest = self._slot(t + 1) if (self.direct and t + 1 < c.n_steps) else None
+            lidar, inertial, last_action, reward, done, _info = self.env.step(torch.max(torch.min(a, self.high), self.low).contiguous(),
+                                                                              terminal=False, out=dest)
+            if dest is None and t + 1 < c.n_steps:   # odd n_envs: the slots are not 16-byte aligned, copy instead
+                for k, src in zip(("lidar", "inertial_data", "last_action"), (lidar, inertial, last_action)):
+                    b.obs[k][t + 1].copy_(src)
             b.rewards[t] = reward * c.reward_scale
             b.dones[t] = done.float()
-            self._obs = {"lidar": lidar, "inertial_data": inertial, "last_action": last_action}
-            ep_rew += float(reward.mean()); ep_n += int(done.sum())
-        _, last_v = self.policy(self._current_obs())
+            ep_rew += reward.mean(); ep_n += done.sum()   # stays on the device: one sync per rollout, not per step
+        self._obs = {"lidar": lidar, "inertial_data": inertial, "last_action": last_action}
+        _, last_v = self.policy(self._obs)
+        ep_rew, ep_n = float(ep_rew), int(ep_n)
         b.finish(last_v, c.gamma, c.gae_lambda)
         self.num_timesteps += c.n_steps * self.env.N
         return {"mean_step_reward": ep_rew / c.n_steps, "episodes_finished": ep_n}

@@ -158,6 +158,31 @@ def test_mixed_waves_fly_exactly_what_dense_waves_would(task, N, T):
     mixed.close(); dense.close()
 
 
+def test_step_writes_the_observation_where_the_caller_wants_it():
+    """te_step takes destination pointers: BatchedEnv.step(out=...) / observe(out=...) put the observation straight into
+    e.g. slot t of a rollout buffer (dronechase_amd/ppo.py), bit-identical to the internal buffers."""
+    torch = _torch()
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+
+    N = 4096
+    a_env, b_env = (BatchedEnv(default_config("stage03", n_envs=N, seed=2), "cuda:0") for _ in range(2))
+    rollout = (torch.zeros((8, N, 3, 13, 26), device="cuda:0"), torch.zeros((8, N, 15), device="cuda:0"), torch.zeros((8, N, 4), device="cuda:0"))
+    a_env.reset(); b_env.reset()
+    for x, y in zip(a_env.observe(), b_env.observe(out=tuple(r[0] for r in rollout))):
+        assert torch.equal(x, y)
+    for t in range(1, 8):
+        act = a_env.random_actions(3, 50 + t)
+        ra, rb = a_env.step(act), b_env.step(act, out=tuple(r[t] for r in rollout))
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y)
+        assert rb[0].data_ptr() == rollout[0][t].data_ptr()
+    assert bool((rollout[0] <= 1).all()) and bool((rollout[1][1:].abs().sum((1, 2)) > 0).all())   # every slot was written
+    with pytest.raises(ValueError, match="16-byte"):
+        b_env.step(act, out=(rollout[0][0].view(-1)[1:-1013].view(N - 1, 3, 13, 26)[:0], rollout[1][0], rollout[2][0]))
+    a_env.close(); b_env.close()
+
+
 def test_stage03_episode_statistics():
     """Long random-action rollout at full size: episodes end, waves advance, kills happen, and the
     terminal observation rows are only written for done envs."""

@@ -45,7 +45,8 @@ def test_gae_against_a_naive_loop():
 
 
 @pytest.mark.gpu
-def test_short_training_run_on_device():
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_short_training_run_on_device(use_graph):
     import torch
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
@@ -53,7 +54,7 @@ def test_short_training_run_on_device():
     from dronechase_amd.batched_env import BatchedEnv
     from dronechase_amd.ppo import PPO, PPOConfig
     env = BatchedEnv(default_config("stage03", n_envs=512, max_step=40), "cuda:0")
-    ppo = PPO(env, PPOConfig(n_steps=16, batch_size=2048, n_epochs=2), seed=1)
+    ppo = PPO(env, PPOConfig(n_steps=16, batch_size=2048, n_epochs=2, use_graph=use_graph), seed=1)
     before = [p.detach().clone() for p in ppo.policy.parameters()]
     logs = []
     ppo.learn(2 * 16 * 512, log=logs.append)
@@ -65,4 +66,13 @@ def test_short_training_run_on_device():
     assert any(not torch.equal(a, b) for a, b in zip(before, ppo.policy.parameters()))
     # the rollout never left the device
     assert all(t.device.type == "cuda" for t in ppo.buf.obs.values()) and ppo.buf.adv.device.type == "cuda"
+    # the buffer holds a real rollout: consecutive observations differ, actions were stored, the step counter of the
+    # environments advanced by exactly the collected steps (the graph's warm-up and capture steps were rolled back)
+    b = ppo.buf
+    assert bool((b.obs["inertial_data"][0] != b.obs["inertial_data"][5]).any()) and bool((b.actions.abs().sum((1, 2)) > 0).all())
+    assert bool(torch.isfinite(b.values).all()) and bool(torch.isfinite(b.logp).all())
+    from dronechase_amd import config as K
+    w = env.get_state().view(torch.int32)
+    steps = w[512 * env.D * K.DRONE_WORDS:].view(512, K.ENV_WORDS)[:, K.E["STEP"]]
+    assert int(steps.max()) <= 2 * 16 and int(steps.max()) >= 16
     env.close()
