@@ -664,7 +664,9 @@ struct te_env {
   size_t lds_bytes;
   size_t stack_lds_bytes = 0;  // stacked_kernel (level5)
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
-  int n_fill_waves = 256;  // fill waves of the sub-step kernel (one per CU of an MI355X); TE_FILL_WAVES overrides
+  int n_fill_waves = 256;  // fill waves of the sub-step kernel: one per CU of an MI355X; four per CU for the six-sphere background of
+                           // level5, where ~9 flight waves per SIMD would leave one fill wave too small a share of the issue slots
+                           // (605 -> 567 us/step; 512 / 1024 fill waves cost stage03 7 / 40 %); TE_FILL_WAVES overrides
   // profiling (te_profile_begin / te_profile_end)
   std::vector<hipEvent_t> events;
   int prof_cap = 0, prof_used = 0;
@@ -743,6 +745,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   e->lds_bytes = (size_t)lds_rows(D, cfg->n_pursuers) * kEPB * sizeof(uint32_t);
   e->p.dense_min = kDenseMin;
   if (const char* v = getenv("TE_DENSE_MIN")) { int n = atoi(v); if (n >= 1 && n <= 65) e->p.dense_min = n; }
+  if (cfg->stacked_obs) e->n_fill_waves = 1024;
   if (const char* v = getenv("TE_FILL_WAVES")) { int n = atoi(v); if (n >= 1 && n <= (1 << 20)) e->n_fill_waves = n; }
   {
     hipError_t le = hipSuccess;
