@@ -73,7 +73,7 @@ class Config(C.Structure):
         ("ally_speed", C.c_float), ("ally_policy", C.c_int32), ("approach_bonus_gain", C.c_float),
         ("catch_distance", C.c_float), ("building_position", C.c_float * 3),
         ("motor_noise", C.c_int32), ("auto_reset", C.c_int32), ("kamikaze_cone_check", C.c_int32), ("stacked_obs", C.c_int32),
-        ("evaluation", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("evaluation", C.c_int32), ("ground_contact", C.c_int32), ("ground_z", C.c_float), ("hull_half_height", C.c_float),
         ("quad", QuadParams),
     ]
 

@@ -65,6 +65,7 @@ TE_API int te_config_default(te_config* c, int32_t task) {
   memset(c, 0, sizeof *c);
   c->struct_size = (uint32_t)sizeof *c;
   c->task = task;
+  c->ground_contact = 0; c->ground_z = -6.0f; c->hull_half_height = 0.0125f; /* plane.urdf at z = -6 (entities_manager.py:120-124): opt-in */
   c->n_envs = 1;
   c->seed = 0;
   c->max_speed = (float)(10.0 * 1000.0 / 3600.0); /* quadcopter.py:590-600 */

@@ -31,7 +31,8 @@ struct Derived {
   float dt_inv_ix, dt_inv_iy, dt_inv_iz, ix, iy, iz, dt_inv_m, dt_g, pwm_floor;
   // PID gains with the controller period folded in: ki * T and kd / T
   float lv_kiT[2], lv_kdT[2], av_kiT[3], av_kdT[3], zv_kiT, zv_kdT;
-  float half_dt, quarter_dt2, noise_m2ln2;  // dt/2, dt^2/4, -2 ln 2 * noise_ratio^2 (Box-Muller radius incl. the noise gain)
+  float half_dt, quarter_dt2, noise_m2ln2;
+  float ground_rest;  // z of a hull resting on the ground plane (ground_z + hull_half_height); used when cfg.ground_contact  // dt/2, dt^2/4, -2 ln 2 * noise_ratio^2 (Box-Muller radius incl. the noise gain)
 };
 constexpr int kMixedWaves = 2, kMixedCap = 64 * kMixedWaves;  // mixed waves per chunk; a slot that would overflow the list flies densely
 constexpr int kDenseMin = 40;                                // default of Params::dense_min: armed envs of a chunk from which a slot gets its own wave
@@ -272,6 +273,7 @@ __host__ __device__ inline Derived derive(const te_config& c) {
   d.zv_kiT = q.z_vel_ki * c.control_dt; d.zv_kdT = q.z_vel_kd / c.control_dt;
   d.half_dt = 0.5f * c.physics_dt; d.quarter_dt2 = 0.25f * c.physics_dt * c.physics_dt;
   d.noise_m2ln2 = -2.0f * 0.69314718056f * q.noise_ratio * q.noise_ratio;
+  d.ground_rest = c.ground_z + c.hull_half_height;
   return d;
 }
 
@@ -318,7 +320,7 @@ TE_DEV void motor_noise_from(uint32_t a, uint32_t b, float m2ln2_gain2, float nz
 //    right of q;
 //  * cos/sin(yaw) come from the first column of R instead of sincos(atan2(.));
 //  * sin/cos of the half rotation angle (< 0.5 rad per 1/240 s for any sane rate) by Taylor polynomials.
-template <bool MODE7, bool CAPTURE, bool NOISE>
+template <bool MODE7, bool CAPTURE, bool NOISE, bool GROUND = false>
 TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float sp[4], uint32_t noise_a, uint32_t noise_b,
                     V3& pend_f, V3& pend_t) {
   const te_quad_params& qp = c.quad;
@@ -406,6 +408,16 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
   b.wb = V3{b.wb.x + k.dt_inv_ix * (Tb.x - gy.x), b.wb.y + k.dt_inv_iy * (Tb.y - gy.y), b.wb.z + k.dt_inv_iz * (Tb.z - gy.z)};
   b.vel = V3{b.vel.x + k.dt_inv_m * Fw.x, b.vel.y + k.dt_inv_m * Fw.y, b.vel.z + (k.dt_inv_m * Fw.z - k.dt_g)};
   b.pos = V3{b.pos.x + dt * b.vel.x, b.pos.y + dt * b.vel.y, b.pos.z + dt * b.vel.z};
+  if (GROUND && c.ground_contact && b.pos.z < k.ground_rest) {  // opt-in ground plane (config-uniform test first): inelastic normal
+    // contact, Coulomb friction mu = 0.5 (Bullet's default 0.5 x plane.urdf's 1.0) against the normal impulse; unpinned
+    const float jn = fmaxf(-b.vel.z, 0.0f);
+    b.pos.z = k.ground_rest; b.vel.z = fmaxf(b.vel.z, 0.0f);
+    const float vt2 = b.vel.x * b.vel.x + b.vel.y * b.vel.y;
+    if (vt2 > 0.0f) {
+      const float vt = fsqrt(vt2), keep = fmaxf(vt - 0.5f * jn, 0.0f) * rcp(vt);
+      b.vel.x *= keep; b.vel.y *= keep;
+    }
+  }
   float w2 = b.wb.x * b.wb.x + b.wb.y * b.wb.y + b.wb.z * b.wb.z;
   float h2 = k.quarter_dt2 * w2;  // (half angle)^2
   float sc, ch;                     // sin(h)/|w| and cos(h)

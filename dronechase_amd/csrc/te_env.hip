@@ -157,6 +157,7 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
   // registers are not live (and conditionally written) across it.
   const int S = c.substeps;
   const Derived& kd = p.kd;
+  constexpr bool kGround = FAMILY == FAM_LEVEL4;  // the opt-in ground plane (cfg.ground_contact) is compiled into the level4 family only
   // One Philox call feeds two consecutive sub-steps: words {x,y} go to the even one, {z,w} wait in two
   // registers for the odd one.
   const int n_plain = c.observe_lag ? S - 1 : S;
@@ -177,12 +178,12 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
   for (int s = 0; s < n_plain; ++s) {
     TE_DRAW(s)
     if (mode7) substep<true, false, NOISE>(c, kd, b, sp, na, nb, pf, pt);  // wave-uniform: slot is per wave
-    else substep<false, false, NOISE>(c, kd, b, sp, na, nb, pf, pt);
+    else substep<false, false, NOISE, kGround>(c, kd, b, sp, na, nb, pf, pt);
   }
   if (c.observe_lag) {
     TE_DRAW(S - 1)
     if (mode7) substep<true, true, NOISE>(c, kd, b, sp, na, nb, pf, pt);
-    else substep<false, true, NOISE>(c, kd, b, sp, na, nb, pf, pt);
+    else substep<false, true, NOISE, kGround>(c, kd, b, sp, na, nb, pf, pt);
   }
 #undef TE_DRAW
 
@@ -720,6 +721,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->n_pursuers < 1 || cfg->n_invaders < 1 || D > kMaxD) return fail("te_create: need 1 <= P, 1 <= I, P + I <= 32");
   if (cfg->substeps < 1 || cfg->substeps > 255) return fail("te_create: substeps out of range");
   if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_EVALUATION) return fail("te_create: unknown task");
+  if (cfg->ground_contact && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: cfg.ground_contact is built for the level4 task family only");
   if (cfg->evaluation && !(family_of(cfg->task) == FAM_LEVEL4 && cfg->ally_policy == TE_ALLY_BT && !cfg->stacked_obs))
     return fail("te_create: cfg.evaluation (Evaluation_Task rules) is the level4 task family with behaviour-tree drivers and the own-sphere observation");
   if (cfg->ally_policy == TE_ALLY_EXTERNAL && !(family_of(cfg->task) == FAM_LEVEL4 && cfg->n_pursuers == 2))

@@ -153,7 +153,12 @@ typedef struct te_config {
                              invaders-in-origin rule (:397), termination = time limit only if max_step > 0 (TIME_IS_LIMITED,
                              :519-524), all rounds over, anybody outside the dome, all pursuers destroyed (:526-551); kills are
                              counted per wingman (TE_D_KILLS) for te_wingman_info */
-  int32_t reserved[3];
+  int32_t ground_contact; /* 1: ground plane (OPT-IN, off in every preset; parity unpinned): the reference loads plane.urdf at
+                             z = -6 (entities_manager.py:120-124, immovable_structures.py:123-135); a drone whose hull bottom
+                             reaches it stops there: inelastic normal contact (Bullet's default restitution 0) and Coulomb
+                             friction 0.5 on the tangential velocity; no contact torque, no drone-drone contact */
+  float ground_z;         /* -6 */
+  float hull_half_height; /* 0.0125: half of the cf2x collision cylinder's height (unverified) */
 
   te_quad_params quad;
 } te_config;

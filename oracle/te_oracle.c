@@ -339,6 +339,21 @@ static void integrate(const te_config* c, ote_drone* d, const real Fw[3], const 
   d->vel[1] += dt * Fw[1] * inv_m;
   d->vel[2] += dt * (Fw[2] * inv_m - (real)q->gravity);
   for (int i = 0; i < 3; ++i) d->pos[i] += dt * d->vel[i];
+  if (c->ground_contact) { /* opt-in ground plane at ground_z (plane.urdf, entities_manager.py:120-124): inelastic normal contact,
+                              Coulomb friction 0.5 against the normal impulse, no contact torque.  Parity unpinned (needs Bullet). */
+    const real rest = (real)c->ground_z + (real)c->hull_half_height;
+    if (d->pos[2] < rest) {
+      real jn = d->vel[2] < 0 ? -d->vel[2] : 0;
+      d->pos[2] = rest;
+      if (d->vel[2] < 0) d->vel[2] = 0;
+      real vt = sqrt(d->vel[0] * d->vel[0] + d->vel[1] * d->vel[1]);
+      if (vt > 0) {
+        real keep = vt - (real)0.5 * jn;
+        keep = keep > 0 ? keep / vt : 0;
+        d->vel[0] *= keep; d->vel[1] *= keep;
+      }
+    }
+  }
   /* attitude: q <- exp(dt w / 2) * q, world-frame w */
   real wmag = norm3(d->omega);
   real dq[4];

@@ -131,3 +131,49 @@ def test_stage_scenarios_match_oracle():
                 diff, imis = _compare_states(orc.get_state(), gpu.get_state().cpu().numpy().view(np.uint32), 1, cfg.n_drones)
                 assert not imis.any() and diff.max() < 1e-4, (task, noise, s, diff.max())
             gpu.close(); orc.close()
+
+
+def test_ground_contact_parity():
+    """cfg.ground_contact (opt-in, parity with PyBullet unpinned: tests/test_oracle_ground.py): the kernel against the
+    oracle on drones that are thrown at the plane.  2 048 evaluation envs, the wingman's z-velocity set to -3 m/s at random
+    heights up to 0.6 m above the plane, then 6 free-running env-steps compared state by state (STATE_TOL 1e-4 after the first
+    step from the identical state; 1e-3 along the rollout, as tests/test_gpu_parity.py::test_rollout_parity_from_reset)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    from dronechase_amd import config as K, default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    from oracle import te_oracle as O
+    from tests._blob import Blob
+    from tests.test_gpu_parity import _compare_states
+
+    N = 2048
+    cfg = default_config("evaluation", n_envs=N, motor_noise=1, seed=3, ground_contact=1, auto_reset=0)
+    D = cfg.n_drones
+    rest = cfg.ground_z + cfg.hull_half_height
+    orc, gpu = O.OracleEnv(cfg, "f32", threads=8), BatchedEnv(cfg, "cuda:0")
+    orc.reset()
+    b = Blob(orc.get_state(), N, D)
+    rng = np.random.default_rng(0)
+    for e in range(N):
+        z = rest + float(rng.uniform(0.01, 0.6))
+        b.place(e, 0, (float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)), z)); b.hover_ready(e, 0, cfg)
+        b.set_f(e, 0, "VEL", [float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), -3.0])
+    orc.set_state(b.w); gpu.set_state(torch.from_numpy(b.w.view(np.int32)).cuda())
+    a = np.zeros((N, 4), np.float32)
+    touched = np.zeros(N, bool)
+    for t in range(6):
+        orc.step(a); gpu.step(torch.from_numpy(a).cuda())
+        so, sg = orc.get_state(), gpu.get_state().cpu().numpy().view(np.uint32)
+        diff, imis = _compare_states(so, sg, N, D)
+        ok = orc.state_margins() > 1e-3
+        assert not (imis & ok).any()
+        assert diff[ok & ~imis].max() < (1e-4 if t == 0 else 1e-3), (t, diff[ok & ~imis].max())
+        z = Blob(sg, N, D).dr[:, 0, K.D["POS"] + 2].view(np.float32)
+        assert (z >= rest - 1e-5).all()
+        touched |= z < rest + 1e-3
+    assert touched.mean() > 0.1        # a share of the hulls sat on the plane at a step boundary (most touch it between two)
+    from dronechase_amd import _lib
+    with pytest.raises(_lib.TEError, match="level4 task family"):
+        BatchedEnv(default_config("stage02", n_envs=64, ground_contact=1), "cuda:0")
+    gpu.close(); orc.close()
