@@ -567,6 +567,82 @@ __global__ __launch_bounds__(256) void observe_ally_kernel(Params p, float* __re
     base[2 * TE_LIDAR_CELLS + cell] = 0.1f;
   }
 }
+// The same observation as two launches for full-size batches (48 us instead of 64 at 65 536 envs):
+//   ally_view_kernel   single-wave workgroups: `n_fill` of them stream the background in the sub-step kernel's fill-wave
+//                      shape while one wave per chunk (lane = env) computes cells / ranges / owners and leaves them as
+//                      (cell | type << 16, r_hat) planes in a scratch buffer, and writes the inertial / last-action rows;
+//   ally_patch_kernel  one thread per (env, drone): the owners' three floats into the finished background.
+__global__ __launch_bounds__(64) void ally_view_kernel(Params p, float* __restrict__ lidar, uint32_t quads, uint32_t n_fill,
+                                                       float* __restrict__ inertial, float* __restrict__ last_action,
+                                                       uint8_t* __restrict__ active, uint32_t* __restrict__ scratch) {
+  __shared__ uint32_t s_cell[kMaxD * kEPB];
+  __shared__ float s_rhat[kMaxD * kEPB];
+  const int l = threadIdx.x;
+  if (blockIdx.x < n_fill) {
+    const uint32_t stride = n_fill * 64u;
+    for (uint32_t q = blockIdx.x * 64u + (uint32_t)l; q < quads; q += stride) TE_FILL_STORE(reinterpret_cast<float4*>(lidar) + q);
+    return;
+  }
+  const te_config& c = p.cfg;
+  const int me = 1, D = p.D;
+  const int env = (int)(blockIdx.x - n_fill) * kEPB + l;
+  const bool valid = env < p.N;
+  const GView v{p.dstate, p.estate, D, p.Npad, env, c.n_pursuers};   // planes are padded to Npad: in bounds for every lane
+  const int step = v.egi(TE_E_STEP);
+  const bool sees = valid && step != 0;
+  if (sees) {
+    const Q4 q = quat_of_euler(V3{v.gf(TE_D_OBS_EULER, me), v.gf(TE_D_OBS_EULER + 1, me), v.gf(TE_D_OBS_EULER + 2, me)});
+    const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    const M3 R = rotation(Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2});
+    const V3 own = obs_pos(v, me);
+    for (int j = 0; j < D; ++j) {
+      uint32_t cell = 0xFFFFFFFFu; float rhat = 1.0f;
+      if (j != me && v.gi(TE_D_ARMED, j)) { int cj; lidar_cell(c, mul(R, sub(obs_pos(v, j), own)), cj, rhat); cell = (uint32_t)cj; }
+      s_cell[j * kEPB + l] = cell; s_rhat[j * kEPB + l] = rhat;
+    }
+  }
+  if (valid) {
+    if (active) active[env] = v.gi(TE_D_ARMED, me) ? 1 : 0;
+    if (last_action)
+      reinterpret_cast<float4*>(last_action)[env] = make_float4(v.gf(TE_D_ALLY_ACTION, me), v.gf(TE_D_ALLY_ACTION + 1, me),
+                                                                 v.gf(TE_D_ALLY_ACTION + 2, me), v.gf(TE_D_ALLY_ACTION + 3, me));
+    if (inertial) {
+      float in[TE_OBS_INERTIAL_WORDS];
+      inertial_obs(c, v, step, in, me);
+#pragma unroll
+      for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) inertial[(size_t)env * TE_OBS_INERTIAL_WORDS + k] = in[k];
+    }
+  }
+  // owner of a cell = smallest range, the earlier slot on ties; a feature clipped to 1.0 never enters an empty cell
+  // (each lane reads back only what it wrote: no barrier)
+  for (int j = 0; j < D; ++j) {
+    uint32_t out = 0xFFFFFFFFu; float rh = 1.0f;
+    if (sees) {
+      const uint32_t cell = s_cell[j * kEPB + l];
+      const float rhat = s_rhat[j * kEPB + l];
+      if (cell != 0xFFFFFFFFu && rhat < 1.0f) {
+        bool owner = true;
+        for (int k = 0; k < D; ++k) {
+          if (k == j || s_cell[k * kEPB + l] != cell) continue;
+          const float rk = s_rhat[k * kEPB + l];
+          if (rk < rhat || (rk == rhat && k < j)) owner = false;
+        }
+        if (owner) { out = cell | ((uint32_t)(j < c.n_pursuers ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) << 16); rh = rhat; }
+      }
+    }
+    scratch[(size_t)(2 * j) * p.Npad + env] = out; scratch[(size_t)(2 * j + 1) * p.Npad + env] = __float_as_uint(rh);
+  }
+}
+__global__ __launch_bounds__(256) void ally_patch_kernel(Params p, float* __restrict__ lidar, const uint32_t* __restrict__ scratch) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)p.D * p.Npad) return;
+  const int j = (int)(i / p.Npad), env = (int)(i - (size_t)j * p.Npad);
+  if (env >= p.N) return;
+  const uint32_t w = scratch[(size_t)(2 * j) * p.Npad + env];
+  if (w == 0xFFFFFFFFu) return;
+  float* d = lidar + (size_t)env * TE_OBS_LIDAR_WORDS + (w & 0xFFFFu);
+  d[0] = __uint_as_float(scratch[(size_t)(2 * j + 1) * p.Npad + env]); d[TE_LIDAR_CELLS] = (float)(w >> 16) / 5.0f; d[2 * TE_LIDAR_CELLS] = 0.1f;
+}
 // exp05: pursuer.drive(action) of drive_lw_rl_agent (exp05_vFinal_task.py:255-260; quadcopter.py:379-413) for armed allies
 __global__ __launch_bounds__(256) void set_ally_actions_kernel(Params p, const float* __restrict__ actions) {
   const int env = blockIdx.x * 256 + threadIdx.x;
@@ -665,6 +741,7 @@ struct te_env {
   size_t lds_bytes;
   size_t stack_lds_bytes = 0;  // stacked_kernel (level5)
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
+  uint32_t* ally_scratch = nullptr;  // te_observe_ally: owner planes between its two launches (allocated on first use)
   int n_fill_waves = 256;  // fill waves of the sub-step kernel: one per CU of an MI355X; four per CU for the six-sphere background of
                            // level5, where ~9 flight waves per SIMD would leave one fill wave too small a share of the issue slots
                            // (605 -> 567 us/step; 512 / 1024 fill waves cost stage03 7 / 40 %); TE_FILL_WAVES overrides
@@ -816,6 +893,7 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
   (void)hipFree(e->p.dstate);
   (void)hipFree(e->p.estate);
+  (void)hipFree(e->ally_scratch);
   (void)hipFree(e->p.slot_mask); (void)hipFree(e->p.mixed_count); (void)hipFree(e->p.mixed_items);
   (void)hipFree(e->p.stage_tab);
   if (e->p.snap) (void)hipFree(e->p.snap);
@@ -864,7 +942,17 @@ __attribute__((visibility("default"))) int te_observe_ally(te_env* e, float* all
     return fail("te_observe_ally: ally_lidar and ally_last_action must be 16-byte aligned");
   DeviceGuard guard(e->device);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(observe_ally_kernel, dim3((e->p.N + kEPB - 1) / kEPB), dim3(256), 0, st, e->p, ally_lidar, ally_inertial, ally_last_action, ally_active);
+  const size_t n_floats = (size_t)e->p.N * TE_OBS_LIDAR_WORDS;
+  const int nchunks = e->p.Npad / kEPB;
+  if (ally_lidar && (n_floats & 3) == 0 && (n_floats >> 2) < (1ull << 32) && e->p.N >= 4096) {  // full-size batches: two launches
+    if (!e->ally_scratch && hipMalloc(&e->ally_scratch, (size_t)2 * e->p.D * e->p.Npad * 4) != hipSuccess)
+      return fail("te_observe_ally: hipMalloc failed");
+    hipLaunchKernelGGL(ally_view_kernel, dim3(256 + nchunks), dim3(64), 0, st, e->p, ally_lidar, (uint32_t)(n_floats >> 2), 256u, ally_inertial,
+                       ally_last_action, ally_active, e->ally_scratch);
+    hipLaunchKernelGGL(ally_patch_kernel, dim3((unsigned)(((size_t)e->p.D * e->p.Npad + 255) / 256)), dim3(256), 0, st, e->p, ally_lidar, e->ally_scratch);
+  } else {
+    hipLaunchKernelGGL(observe_ally_kernel, dim3(nchunks), dim3(256), 0, st, e->p, ally_lidar, ally_inertial, ally_last_action, ally_active);
+  }
   TE_HIP(hipGetLastError());
   return 0;
 }

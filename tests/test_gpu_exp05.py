@@ -24,7 +24,7 @@ def test_exp05_single_step_parity_with_a_driven_ally(noise):
     from dronechase_amd.batched_env import BatchedEnv
     from oracle import te_oracle as O
 
-    N = 2048
+    N = 4096 if noise else 2048     # 4 096: te_observe_ally's two-launch path (background waves + owner planes, then patches); below: one launch
     cfg = default_config("exp05", n_envs=N, motor_noise=noise, seed=31)
     D = cfg.n_drones
     orc, gpu = O.OracleEnv(cfg, "f32", threads=8), BatchedEnv(cfg, "cuda:0")
