@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libthreaten
 EXPORTS = (
     "te_config_default", "te_create", "te_destroy", "te_reset", "te_observe", "te_step", "te_random_actions",
     "te_state_words", "te_get_state", "te_set_state", "te_algorithmic_bytes_per_env_step", "te_profile_begin",
-    "te_profile_end", "te_debug_stamps", "te_abi_version", "te_last_error", "te_step_stacked", "te_observe_stacked", "te_observe_ally", "te_set_ally_actions", "te_wingman_info", "te_calculate_rounds",
+    "te_profile_end", "te_debug_stamps", "te_abi_version", "te_last_error", "te_step_stacked", "te_observe_stacked", "te_observe_ally", "te_set_ally_actions", "te_wingman_info", "te_calculate_rounds", "te_observe_wingman", "te_set_wingman_actions",
 )
 
 
@@ -49,6 +49,8 @@ def load() -> C.CDLL:
     L.te_set_ally_actions.argtypes = [vp, vp, vp]
     L.te_wingman_info.argtypes = [vp, vp, vp]
     L.te_calculate_rounds.argtypes = [C.c_int32, C.c_int32]
+    L.te_observe_wingman.argtypes = [vp, C.c_int32] + [vp] * 4 + [vp]
+    L.te_set_wingman_actions.argtypes = [vp, C.c_int32, vp, vp]
     L.te_random_actions.argtypes = [vp, vp, u64, u64, vp]
     L.te_state_words.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.te_get_state.argtypes = [vp, vp, C.c_size_t, vp]

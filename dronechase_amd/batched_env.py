@@ -122,16 +122,30 @@ class BatchedEnv:
                                           self._p(t[0]), self._p(t[1]), self._p(t[2]), self._p(t[3]), self._stream()), "te_step_stacked")
         return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
 
-    # exp05 ----------------------------------------------------------------------------------
+    # caller-driven wingmen (exp05's ally, "nn" drivers of the evaluation task) -----------------
+    def observe_wingman(self, wingman: int):
+        """Observation of a caller-driven pursuer on the current state (compute_lw_observation, exp05_vFinal_task.py:265-292,
+        evaluation_task.py:281-310): (lidar [N,3,13,26], inertial [N,15], last_action [N,4], active [N] u8)."""
+        if not hasattr(self, "_wingman_buf"):
+            self._wingman_buf = {}
+        if wingman not in self._wingman_buf:
+            self._wingman_buf[wingman] = (torch.empty_like(self.lidar), torch.empty_like(self.inertial), torch.empty_like(self.last_action),
+                                          torch.empty((self.N,), dtype=torch.uint8, device=self.device))
+        lidar, inertial, last_action, active = self._wingman_buf[wingman]
+        _lib.check(self.L.te_observe_wingman(self._h, int(wingman), self._p(lidar), self._p(inertial), self._p(last_action), self._p(active),
+                                             self._stream()), "te_observe_wingman")
+        return lidar, inertial, last_action, active
+
+    def set_wingman_actions(self, wingman: int, actions: torch.Tensor) -> None:
+        """`pursuer.drive(action)` for every env whose pursuer `wingman` is armed."""
+        a = self._check_actions(actions)
+        _lib.check(self.L.te_set_wingman_actions(self._h, int(wingman), self._p(a), self._stream()), "te_set_wingman_actions")
+
     def observe_ally(self):
-        """Observation of pursuer 1 on the current state (Exp05_vFinal_Task.compute_lw_observation,
-        exp05_vFinal_task.py:265-292): (lidar [N,3,13,26], inertial [N,15], last_action [N,4], active [N] u8)."""
-        if not hasattr(self, "ally_lidar"):
-            self.ally_lidar, self.ally_inertial = torch.empty_like(self.lidar), torch.empty_like(self.inertial)
-            self.ally_last_action = torch.empty_like(self.last_action)
-            self.ally_active = torch.empty((self.N,), dtype=torch.uint8, device=self.device)
-        _lib.check(self.L.te_observe_ally(self._h, self._p(self.ally_lidar), self._p(self.ally_inertial), self._p(self.ally_last_action),
-                                          self._p(self.ally_active), self._stream()), "te_observe_ally")
+        """exp05: the ally = pursuer 1 (Exp05_vFinal_Task.compute_lw_observation)."""
+        if int(self.cfg.ally_policy) != K.ALLY_EXTERNAL:
+            _lib.check(self.L.te_observe_ally(self._h, None, None, None, None, self._stream()), "te_observe_ally")  # raises with the library's message
+        self.ally_lidar, self.ally_inertial, self.ally_last_action, self.ally_active = self.observe_wingman(1)
         return self.ally_lidar, self.ally_inertial, self.ally_last_action, self.ally_active
 
     def set_ally_actions(self, actions: torch.Tensor) -> None:

@@ -500,12 +500,12 @@ __global__ __launch_bounds__(256) void fill_ones_kernel(float* __restrict__ dst,
 // range of every other armed drone seen from the ally's IMU attitude into LDS, all threads stream the chunk's tile
 // (ones), then the owner of each cell is patched in.  Same rules as the agent's sphere: closer wins in slot order, empty
 // right after a reset.
-__global__ __launch_bounds__(256) void observe_ally_kernel(Params p, float* __restrict__ lidar, float* __restrict__ inertial,
+__global__ __launch_bounds__(256) void observe_ally_kernel(Params p, int me, float* __restrict__ lidar, float* __restrict__ inertial,
                                                            float* __restrict__ last_action, uint8_t* __restrict__ active) {
   __shared__ uint32_t s_cell[kMaxD * kEPB];
   __shared__ float s_rhat[kMaxD * kEPB];
   const te_config& c = p.cfg;
-  const int me = 1, D = p.D;
+  const int D = p.D;
   const int env0 = blockIdx.x * kEPB, nvalid = min(kEPB, p.N - env0);
   const int l = threadIdx.x & (kEPB - 1), w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const bool valid = l < nvalid;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void observe_ally_kernel(Params p, float* __re
 //                      shape while one wave per chunk (lane = env) computes cells / ranges / owners and leaves them as
 //                      (cell | type << 16, r_hat) planes in a scratch buffer, and writes the inertial / last-action rows;
 //   ally_patch_kernel  one thread per (env, drone): the owners' three floats into the finished background.
-__global__ __launch_bounds__(64) void ally_view_kernel(Params p, float* __restrict__ lidar, uint32_t quads, uint32_t n_fill,
+__global__ __launch_bounds__(64) void ally_view_kernel(Params p, int me, float* __restrict__ lidar, uint32_t quads, uint32_t n_fill,
                                                        float* __restrict__ inertial, float* __restrict__ last_action,
                                                        uint8_t* __restrict__ active, uint32_t* __restrict__ scratch) {
   __shared__ uint32_t s_cell[kMaxD * kEPB];
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64) void ally_view_kernel(Params p, float* __restri
     return;
   }
   const te_config& c = p.cfg;
-  const int me = 1, D = p.D;
+  const int D = p.D;
   const int env = (int)(blockIdx.x - n_fill) * kEPB + l;
   const bool valid = env < p.N;
   const GView v{p.dstate, p.estate, D, p.Npad, env, c.n_pursuers};   // planes are padded to Npad: in bounds for every lane
@@ -644,10 +644,9 @@ __global__ __launch_bounds__(256) void ally_patch_kernel(Params p, float* __rest
   d[0] = __uint_as_float(scratch[(size_t)(2 * j + 1) * p.Npad + env]); d[TE_LIDAR_CELLS] = (float)(w >> 16) / 5.0f; d[2 * TE_LIDAR_CELLS] = 0.1f;
 }
 // exp05: pursuer.drive(action) of drive_lw_rl_agent (exp05_vFinal_task.py:255-260; quadcopter.py:379-413) for armed allies
-__global__ __launch_bounds__(256) void set_ally_actions_kernel(Params p, const float* __restrict__ actions) {
+__global__ __launch_bounds__(256) void set_ally_actions_kernel(Params p, int me, const float* __restrict__ actions) {
   const int env = blockIdx.x * 256 + threadIdx.x;
   if (env >= p.N) return;
-  const int me = 1;
   const GView v{p.dstate, p.estate, p.D, p.Npad, env, p.cfg.n_pursuers};
   if (!v.gi(TE_D_ARMED, me)) return;
   const float4 a = reinterpret_cast<const float4*>(actions)[env];
@@ -799,6 +798,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->substeps < 1 || cfg->substeps > 255) return fail("te_create: substeps out of range");
   if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_EVALUATION) return fail("te_create: unknown task");
   if (cfg->ground_contact && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: cfg.ground_contact is built for the level4 task family only");
+  if (cfg->evaluation && (((uint32_t)cfg->evaluation >> 8) >> cfg->n_pursuers) != 0u) return fail("te_create: cfg.evaluation's driver mask names a pursuer that does not exist");
   if (cfg->evaluation && !(family_of(cfg->task) == FAM_LEVEL4 && cfg->ally_policy == TE_ALLY_BT && !cfg->stacked_obs))
     return fail("te_create: cfg.evaluation (Evaluation_Task rules) is the level4 task family with behaviour-tree drivers and the own-sphere observation");
   if (cfg->ally_policy == TE_ALLY_EXTERNAL && !(family_of(cfg->task) == FAM_LEVEL4 && cfg->n_pursuers == 2))
@@ -934,37 +934,59 @@ __attribute__((visibility("default"))) int te_wingman_info(te_env* e, int32_t* w
   return 0;
 }
 
-__attribute__((visibility("default"))) int te_observe_ally(te_env* e, float* ally_lidar, float* ally_inertial, float* ally_last_action,
-                                                           uint8_t* ally_active, void* stream) {
-  if (!e) return fail("te_observe_ally: null env");
-  if (e->p.cfg.ally_policy != TE_ALLY_EXTERNAL) return fail("te_observe_ally: this te_env's ally is not driven by the caller (cfg.ally_policy != TE_ALLY_EXTERNAL)");
+static bool wingman_is_callers(const te_env* e, int wingman) {
+  const te_config& c = e->p.cfg;
+  if (wingman < 0 || wingman >= c.n_pursuers) return false;
+  return (c.ally_policy == TE_ALLY_EXTERNAL && wingman == 1) || (((uint32_t)c.evaluation >> (8 + wingman)) & 1u) != 0u;
+}
+
+__attribute__((visibility("default"))) int te_observe_wingman(te_env* e, int32_t wingman, float* ally_lidar, float* ally_inertial,
+                                                              float* ally_last_action, uint8_t* ally_active, void* stream) {
+  if (!e) return fail("te_observe_wingman: null env");
+  if (!wingman_is_callers(e, wingman))
+    return fail("te_observe_wingman: this pursuer is not driven by the caller (exp05: cfg.ally_policy == TE_ALLY_EXTERNAL, pursuer 1; evaluation: the driver mask in cfg.evaluation)");
   if ((ally_lidar && ((uintptr_t)ally_lidar & 15)) || (ally_last_action && ((uintptr_t)ally_last_action & 15)))
-    return fail("te_observe_ally: ally_lidar and ally_last_action must be 16-byte aligned");
+    return fail("te_observe_wingman: lidar and last_action must be 16-byte aligned");
   DeviceGuard guard(e->device);
   hipStream_t st = (hipStream_t)stream;
   const size_t n_floats = (size_t)e->p.N * TE_OBS_LIDAR_WORDS;
   const int nchunks = e->p.Npad / kEPB;
   if (ally_lidar && (n_floats & 3) == 0 && (n_floats >> 2) < (1ull << 32) && e->p.N >= 4096) {  // full-size batches: two launches
     if (!e->ally_scratch && hipMalloc(&e->ally_scratch, (size_t)2 * e->p.D * e->p.Npad * 4) != hipSuccess)
-      return fail("te_observe_ally: hipMalloc failed");
-    hipLaunchKernelGGL(ally_view_kernel, dim3(256 + nchunks), dim3(64), 0, st, e->p, ally_lidar, (uint32_t)(n_floats >> 2), 256u, ally_inertial,
-                       ally_last_action, ally_active, e->ally_scratch);
+      return fail("te_observe_wingman: hipMalloc failed");
+    hipLaunchKernelGGL(ally_view_kernel, dim3(256 + nchunks), dim3(64), 0, st, e->p, (int)wingman, ally_lidar, (uint32_t)(n_floats >> 2), 256u,
+                       ally_inertial, ally_last_action, ally_active, e->ally_scratch);
     hipLaunchKernelGGL(ally_patch_kernel, dim3((unsigned)(((size_t)e->p.D * e->p.Npad + 255) / 256)), dim3(256), 0, st, e->p, ally_lidar, e->ally_scratch);
   } else {
-    hipLaunchKernelGGL(observe_ally_kernel, dim3(nchunks), dim3(256), 0, st, e->p, ally_lidar, ally_inertial, ally_last_action, ally_active);
+    hipLaunchKernelGGL(observe_ally_kernel, dim3(nchunks), dim3(256), 0, st, e->p, (int)wingman, ally_lidar, ally_inertial, ally_last_action, ally_active);
   }
   TE_HIP(hipGetLastError());
   return 0;
+}
+
+__attribute__((visibility("default"))) int te_set_wingman_actions(te_env* e, int32_t wingman, const float* ally_actions, void* stream) {
+  if (!e) return fail("te_set_wingman_actions: null env");
+  if (!wingman_is_callers(e, wingman))
+    return fail("te_set_wingman_actions: this pursuer is not driven by the caller (exp05: cfg.ally_policy == TE_ALLY_EXTERNAL, pursuer 1; evaluation: the driver mask in cfg.evaluation)");
+  if (!ally_actions || ((uintptr_t)ally_actions & 15)) return fail("te_set_wingman_actions: actions ([N,4] f32, 16-byte aligned) is required");
+  DeviceGuard guard(e->device);
+  hipLaunchKernelGGL(set_ally_actions_kernel, dim3((e->p.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->p, (int)wingman, ally_actions);
+  TE_HIP(hipGetLastError());
+  return 0;
+}
+
+__attribute__((visibility("default"))) int te_observe_ally(te_env* e, float* ally_lidar, float* ally_inertial, float* ally_last_action,
+                                                           uint8_t* ally_active, void* stream) {
+  if (!e) return fail("te_observe_ally: null env");
+  if (e->p.cfg.ally_policy != TE_ALLY_EXTERNAL) return fail("te_observe_ally: this te_env's ally is not driven by the caller (cfg.ally_policy != TE_ALLY_EXTERNAL)");
+  return te_observe_wingman(e, 1, ally_lidar, ally_inertial, ally_last_action, ally_active, stream);
 }
 
 __attribute__((visibility("default"))) int te_set_ally_actions(te_env* e, const float* ally_actions, void* stream) {
   if (!e) return fail("te_set_ally_actions: null env");
   if (e->p.cfg.ally_policy != TE_ALLY_EXTERNAL) return fail("te_set_ally_actions: this te_env's ally is not driven by the caller (cfg.ally_policy != TE_ALLY_EXTERNAL)");
   if (!ally_actions || ((uintptr_t)ally_actions & 15)) return fail("te_set_ally_actions: ally_actions ([N,4] f32, 16-byte aligned) is required");
-  DeviceGuard guard(e->device);
-  hipLaunchKernelGGL(set_ally_actions_kernel, dim3((e->p.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->p, ally_actions);
-  TE_HIP(hipGetLastError());
-  return 0;
+  return te_set_wingman_actions(e, 1, ally_actions, stream);
 }
 
 __attribute__((visibility("default"))) int te_observe(te_env* e, float* obs_lidar, float* obs_inertial, float* obs_last_action, void* stream) {

@@ -280,6 +280,11 @@ template <class V> TE_DEV int kamikaze_update(const te_config& c, const V& v, ui
   }
   return next;
 }
+// is pursuer s flown by the caller (te_set_wingman_actions) instead of a scripted driver?  exp05's ally, or a pursuer of
+// the Evaluation_Task driver mask (cfg.evaluation bits 8..)
+TE_DEV bool driven_externally(const te_config& c, int s) {
+  return (c.ally_policy == TE_ALLY_EXTERNAL && s == 1) || (((uint32_t)c.evaluation >> (8 + s)) & 1u) != 0u;
+}
 // command of ONE scripted ally `s` for the NEXT step (LoyalWingmanBehaviorTree.update), stored in the TE_X_CMD
 // planes by the engage/observe kernel, where the pursuer-invader distances are at hand in LDS
 template <class V> TE_DEV void prepare_slot(const te_config& c, const V& v, int s) {
@@ -295,7 +300,8 @@ template <class V> TE_DEV void prepare_slot(const te_config& c, const V& v, int 
     if (s == first) return;
   }
   float out[3] = {0.0f, 0.0f, 0.0f};
-  if (c.ally_policy == TE_ALLY_BT) {  // LoyalWingmanBehaviorTree (loyalwingman_navigator.py:238-352)
+  const bool ext = driven_externally(c, s);
+  if (!ext && c.ally_policy == TE_ALLY_BT) {  // LoyalWingmanBehaviorTree (loyalwingman_navigator.py:238-352)
     V3 me = obs_pos(v, s);
     if (gun_available(c, v.gi(TE_D_MUNITION, s), v.gi(TE_D_LAST_FIRED, s), v.egi(TE_E_STEP))) {
       float dm;
@@ -305,7 +311,7 @@ template <class V> TE_DEV void prepare_slot(const te_config& c, const V& v, int 
     } else {
       cmd_toward(me, V3{v.gf(TE_D_FORMATION, s), v.gf(TE_D_FORMATION + 1, s), v.gf(TE_D_FORMATION + 2, s)}, c.ally_speed, out);
     }
-  } else if (c.ally_policy != TE_ALLY_FROZEN) {  // (frozen: exp04_vFinal_task.py:240-242: drive([0,0,0,1]))
+  } else if (ext || c.ally_policy != TE_ALLY_FROZEN) {  // (frozen: exp04_vFinal_task.py:240-242: drive([0,0,0,1]))
     // nobody, or the caller's policy (te_set_ally_actions, exp05): the set-point persists
     out[0] = v.gf(TE_D_SETPOINT + 0, s); out[1] = v.gf(TE_D_SETPOINT + 1, s); out[2] = v.gf(TE_D_SETPOINT + 3, s);
   }
@@ -343,7 +349,7 @@ template <class V> TE_DEV void level4_spawn_slot(const te_config& c, const V& v,
   } else if (reset) {
     U4 r = env_rng(c, v.env, RNG_SPAWN_PURSUER, (uint32_t)s, 0, episode, 0);
     respawn_armed(c, v, s, level4_position(c, c.pursuer_spawn_radius, u01(r.x), u01(r.y)));
-    if (c.ally_policy == TE_ALLY_EXTERNAL && s == 1) {  // Exp05_vFinal_Task.init_globals: last_action = zeros (exp05_vFinal_task.py:139)
+    if (driven_externally(c, s)) {  // Exp05_vFinal_Task.init_globals: last_action = zeros (exp05_vFinal_task.py:139)
 #pragma unroll
       for (int k = 0; k < 4; ++k) v.sf(TE_D_ALLY_ACTION + k, s, 0.0f);
     }

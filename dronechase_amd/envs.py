@@ -95,9 +95,11 @@ class Exp05vFinalEnvironment(_SingleEnv):  # level4/exp05_vFinal_environment.py
 class EvaluationEnvironment(_SingleEnv):  # level4/evaluation_environment.py (behaviour-tree drivers)
     """`EvaluationEnvironment(configuration, GUI, rl_frequency)`: every wingman is flown by the task
     (evaluation_environment.py:170-187); `configuration["drivers"]` is the reference's list of
-    `{"type": "bt", "name": ...}` (evaluation_exp01_1bt_app_ready.py:64-68).  Drivers of type "nn" need a
-    stable-baselines3 checkpoint (`PPO.load`, evaluation_task.py:658-661) and are refused here; a policy object can fly
-    the ally through Exp05vFinalEnvironment instead.  `step` returns reward 0 and the per-wingman info rows
+    `{"type": "bt", "name": ...}` (evaluation_exp01_1bt_app_ready.py:64-68).  A driver of type "nn" loads a
+    stable-baselines3 checkpoint from `"path"` in the reference (`PPO.load`, evaluation_task.py:658-661); SB3 is not
+    installable here, so it takes the loaded object instead: `{"type": "nn", "name": ..., "model": obj}` with SB3's
+    `predict(observation, deterministic=True)`, asked once per step with that wingman's own observation, as
+    Evaluation_Task.drive_lw does (:257-268).  `step` returns reward 0 and the per-wingman info rows
     `{name: {"lw_kills", "lw_alive", "lw_munitions", "current_wave", "step"}}` of the armed wingmen (:553-574)."""
     TASK = "evaluation"
     INFO_KEYS = ("lw_kills", "lw_alive", "lw_munitions", "current_wave", "step")
@@ -106,9 +108,15 @@ class EvaluationEnvironment(_SingleEnv):  # level4/evaluation_environment.py (be
                  **overrides):
         configuration = dict(configuration or {})
         drivers = configuration.get("drivers", [{"type": "bt", "name": "bt_1"}])
-        if any(d.get("type") != "bt" for d in drivers):
-            raise ValueError("EvaluationEnvironment: only behaviour-tree drivers ({'type': 'bt'}) are built; 'nn' drivers load an SB3 checkpoint")
-        self.driver_names = [d.get("name", f"bt_{i + 1}") for i, d in enumerate(drivers)]
+        for d in drivers:
+            if d.get("type") == "nn" and not hasattr(d.get("model"), "predict"):
+                raise ValueError("EvaluationEnvironment: a driver of type 'nn' needs 'model': an object with SB3's predict() "
+                                 "(the reference's 'path' is a stable-baselines3 checkpoint: load it where SB3 is installed)")
+            if d.get("type") not in ("bt", "nn"):
+                raise ValueError("EvaluationEnvironment: drivers are behaviour-tree ({'type': 'bt'}) or policy ({'type': 'nn', 'model': ...}) wingmen")
+        self.driver_names = [d.get("name", f"{d.get('type')}_{i + 1}") for i, d in enumerate(drivers)]
+        self.models = {p: d["model"] for p, d in enumerate(drivers) if d.get("type") == "nn"}
+        overrides["evaluation"] = 1 | (sum(1 << p for p in self.models) << 8)
         from . import _lib
         P, mun = len(drivers), int(configuration.get("munition_per_defender", 20))
         rounds = int(_lib.load().te_calculate_rounds(P, mun))  # evaluation_task.py:96-100
@@ -120,6 +128,14 @@ class EvaluationEnvironment(_SingleEnv):  # level4/evaluation_environment.py (be
         super().__init__(dome_radius, rl_frequency, GUI, **overrides)
 
     def step(self, actions_not_used=None):
+        import torch
+
+        for p, model in self.models.items():   # Evaluation_Task.drive_lw: observation -> predict -> drive, armed wingmen only
+            lidar, inertial, last_action, active = self._b.observe_wingman(p)
+            if bool(active[0].item()):
+                o = {"lidar": lidar[0].cpu().numpy(), "inertial_data": inertial[0].cpu().numpy(), "last_action": last_action[0].cpu().numpy()}
+                action, _ = model.predict(o, deterministic=True)
+                self._b.set_wingman_actions(p, torch.as_tensor(np.asarray(action, np.float32).reshape(1, 4), device=self._b.device))
         obs, reward, done, truncated, _ = super().step(np.zeros(4, np.float32))
         rows = self._b.wingman_info()[0].cpu().numpy()
         info = {name: dict(zip(self.INFO_KEYS, (int(rows[p, 0]), bool(rows[p, 1]), *(int(x) for x in rows[p, 2:]))))

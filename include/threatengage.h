@@ -152,7 +152,9 @@ typedef struct te_config {
                              (drivers of type "bt", :257-275,655-668; te_step's actions are ignored), reward 0 (:508-515), no
                              invaders-in-origin rule (:397), termination = time limit only if max_step > 0 (TIME_IS_LIMITED,
                              :519-524), all rounds over, anybody outside the dome, all pursuers destroyed (:526-551); kills are
-                             counted per wingman (TE_D_KILLS) for te_wingman_info */
+                             counted per wingman (TE_D_KILLS) for te_wingman_info.  Bits 8.. : mask of the pursuers whose driver
+                             is the CALLER's instead of the behaviour tree (drivers of type "nn", :264-268): bit 8 + p set =
+                             pursuer p is observed with te_observe_wingman and commanded with te_set_wingman_actions */
   int32_t ground_contact; /* 1: ground plane (OPT-IN, off in every preset; parity unpinned): the reference loads plane.urdf at
                              z = -6 (entities_manager.py:120-124, immovable_structures.py:123-135); a drone whose hull bottom
                              reaches it stops there: inelastic normal contact (Bullet's default restitution 0) and Coulomb
@@ -188,7 +190,8 @@ enum {
   TE_D_FORMATION = 45, /* 3  last replace() position (quadcopter.py:437) */
   TE_D_PENDING = 48,   /* 6  world force(3)+torque(3) applied outside the loop, consumed by the next
                              integration (stage01 replace_invader, level2/components/quadcopter_manager.py:166-179) */
-  TE_D_ALLY_ACTION = 48, /* 4  the same words of pursuer 1 under TE_ALLY_EXTERNAL (no level4 drone has a pending wrench):
+  TE_D_ALLY_ACTION = 48, /* 4  the same words of a CALLER-DRIVEN pursuer (pursuer 1 under TE_ALLY_EXTERNAL, the pursuers of
+                             cfg.evaluation's driver mask; no level4 drone has a pending wrench):
                              the ally policy's previous action, Exp05_vFinal_Task.last_action (exp05_vFinal_task.py:139,259) */
   TE_D_ARMED = 54,     /* i32 */
   TE_D_MUNITION = 55,  /* i32 */
@@ -276,6 +279,12 @@ int te_observe_stacked(te_env* env, float* obs_stacked, uint8_t* obs_mask, float
 int te_observe_ally(te_env* env, float* ally_lidar, float* ally_inertial, float* ally_last_action, uint8_t* ally_active,
                     void* stream);
 int te_set_ally_actions(te_env* env, const float* ally_actions, void* stream);
+/* The same pair for ANY caller-driven pursuer `wingman`: pursuer 1 of exp05 (= the two calls above), or a pursuer whose bit
+ * is set in cfg.evaluation's driver mask (Evaluation_Task.drive_lw with a driver that has `predict`,
+ * evaluation_task.py:257-268, compute_lw_observation :281-310).  The last action is kept per wingman (the reference shares
+ * one `self.last_action` between all "nn" drivers of an env, i.e. a wingman sees its predecessor's action: not restated). */
+int te_observe_wingman(te_env* env, int32_t wingman, float* lidar, float* inertial, float* last_action, uint8_t* active, void* stream);
+int te_set_wingman_actions(te_env* env, int32_t wingman, const float* actions, void* stream);
 
 /* Evaluation_Task.compute_info (evaluation_task.py:553-574), cfg.evaluation only: wingman_info [N,P,5] i32 with the rows
  * (lw_kills, lw_alive, lw_munitions, current_wave, step) of every pursuer AFTER the last te_step (the reference lists the

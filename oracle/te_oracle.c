@@ -50,6 +50,7 @@ typedef struct {
   real obs_pos[3], obs_euler[3], obs_vel[3], obs_rate[3];
   real formation[3];
   real pending[6];
+  real ext_action[4]; /* caller-driven pursuer: the driver's last action (exp05_vFinal_task.py:139,259; evaluation_task.py:266); blob: TE_D_ALLY_ACTION */
   int32_t armed, munition, last_fired, nav_state;
 } ote_drone;
 
@@ -61,7 +62,6 @@ typedef struct {
   int32_t episode;
   real last_action[4];
   real prev_snap_min;
-  real ally_action[4]; /* TE_ALLY_EXTERNAL: Exp05_vFinal_Task.last_action (exp05_vFinal_task.py:139,259); blob: TE_D_ALLY_ACTION of pursuer 1 */
 } ote_envrec;
 
 typedef struct ote_env {
@@ -1048,7 +1048,7 @@ static void level4_reset_env(ote_env* E, int e) {
   er->agent_kills = 0; er->allies_kills = 0; er->deads = 0;
   er->last_dist = (real)c->dome_radius;
   for (int k = 0; k < 4; ++k) er->last_action[k] = 0;
-  for (int k = 0; k < 4; ++k) er->ally_action[k] = 0; /* exp05_vFinal_task.py:139 (init_globals) */
+  for (int p = 0; p < c->n_pursuers; ++p) for (int k = 0; k < 4; ++k) dr[p].ext_action[k] = 0; /* exp05_vFinal_task.py:139 (init_globals) */
   for (int i = 0; i < E->D; ++i) disarm(&dr[i]);
   /* on_episode_start */
   level4_setup_round(E, e, er->round);
@@ -1063,6 +1063,10 @@ static void level4_reset_env(ote_env* E, int e) {
   level4_refresh_snapshot(E, e, 1);
 }
 
+/* is pursuer s flown by the caller (ote_set_wingman_actions)?  exp05's ally, or a pursuer of cfg.evaluation's driver mask */
+static int driven_externally(const te_config* c, int s) {
+  return (c->ally_policy == TE_ALLY_EXTERNAL && s == 1) || ((((uint32_t)c->evaluation) >> (8 + s)) & 1u);
+}
 static void note_margin(real* m, real value, real threshold) {
   real d = fabs(value - threshold);
   if (d < *m) *m = d;
@@ -1091,7 +1095,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   /* (2) task.on_step_start (exp03_vFinal_task.py:232-244,276-283) on the CURRENT offsets snapshot */
   for (int j = P; j < D; ++j) if (dr[j].armed) kamikaze_update(c, dr, er->snap_mask, j);
   if (c->evaluation) { /* Evaluation_Task.drive_lw (evaluation_task.py:257-275): every armed pursuer, drivers of type "bt" */
-    for (int p = 0; p < P; ++p) if (dr[p].armed) wingman_update(c, dr, er->snap_mask, p, er->step);
+    for (int p = 0; p < P; ++p) if (dr[p].armed && !driven_externally(c, p)) wingman_update(c, dr, er->snap_mask, p, er->step);
   } else if (dr[0].armed) {
     /* get_armed_pursuers()[1:] : with the agent armed these are the armed allies */
     for (int p = 1; p < P; ++p) {
@@ -1597,38 +1601,46 @@ OTE_API int ote_observe(ote_env* E, float* lidar, float* inertial, float* last_a
   }
   return 0;
 }
-/* exp05: Exp05_vFinal_Task.compute_lw_observation (exp05_vFinal_task.py:265-292) of pursuer 1 on the current state,
- * and the `pursuer.drive(action)` half of drive_lw_rl_agent (:252-260).  The reference loops over
- * get_armed_pursuers()[1:]; the agent is armed at every step boundary (its death ends the episode), so the ally is
- * driven exactly when it is armed. */
-OTE_API int ote_observe_ally(ote_env* E, float* lidar, float* inertial, float* last_action, uint8_t* active) {
+/* Observation and command of a caller-driven pursuer `w`: Exp05_vFinal_Task.compute_lw_observation / drive_lw_rl_agent
+ * (exp05_vFinal_task.py:252-292) for exp05's ally, Evaluation_Task.drive_lw with a `predict` driver (evaluation_task.py:257-310)
+ * for the pursuers of the driver mask.  The reference loops over the ARMED pursuers: a dead one is neither observed nor
+ * driven. */
+OTE_API int ote_observe_wingman(ote_env* E, int w, float* lidar, float* inertial, float* last_action, uint8_t* active) {
   const te_config* c = &E->cfg;
-  if (c->ally_policy != TE_ALLY_EXTERNAL || c->n_pursuers != 2) return 1;
+  if (w < 0 || w >= c->n_pursuers || !driven_externally(c, w)) return 1;
   for (int e = 0; e < c->n_envs; ++e) {
     ote_drone* dr = &E->drones[(size_t)e * E->D];
     ote_envrec* er = &E->envs[e];
     if (lidar) {
       float* L = lidar + (size_t)e * TE_OBS_LIDAR_WORDS;
       if (er->step == 0) for (int i = 0; i < TE_OBS_LIDAR_WORDS; ++i) L[i] = 1.0f; /* as ote_observe */
-      else own_sphere(c, dr, E->D, 1, L);
+      else own_sphere(c, dr, E->D, w, L);
     }
-    if (inertial) inertial_obs(c, &dr[1], er->step, max_munition_of(c, 1), inertial + (size_t)e * TE_OBS_INERTIAL_WORDS);
-    if (last_action) for (int k = 0; k < 4; ++k) last_action[(size_t)e * 4 + k] = (float)er->ally_action[k];
-    if (active) active[e] = dr[1].armed ? 1 : 0;
+    if (inertial) inertial_obs(c, &dr[w], er->step, max_munition_of(c, w), inertial + (size_t)e * TE_OBS_INERTIAL_WORDS);
+    if (last_action) for (int k = 0; k < 4; ++k) last_action[(size_t)e * 4 + k] = (float)dr[w].ext_action[k];
+    if (active) active[e] = dr[w].armed ? 1 : 0;
   }
   return 0;
 }
-OTE_API int ote_set_ally_actions(ote_env* E, const float* actions) {
+OTE_API int ote_set_wingman_actions(ote_env* E, int w, const float* actions) {
   const te_config* c = &E->cfg;
-  if (c->ally_policy != TE_ALLY_EXTERNAL || c->n_pursuers != 2) return 1;
+  if (w < 0 || w >= c->n_pursuers || !driven_externally(c, w)) return 1;
   for (int e = 0; e < c->n_envs; ++e) {
     ote_drone* dr = &E->drones[(size_t)e * E->D];
-    if (!dr[1].armed) continue;
+    if (!dr[w].armed) continue;
     real cmd[4];
-    for (int k = 0; k < 4; ++k) { cmd[k] = (real)actions[(size_t)e * 4 + k]; E->envs[e].ally_action[k] = cmd[k]; }
-    command_to_setpoint(cmd, dr[1].setpoint);
+    for (int k = 0; k < 4; ++k) { cmd[k] = (real)actions[(size_t)e * 4 + k]; dr[w].ext_action[k] = cmd[k]; }
+    command_to_setpoint(cmd, dr[w].setpoint);
   }
   return 0;
+}
+OTE_API int ote_observe_ally(ote_env* E, float* lidar, float* inertial, float* last_action, uint8_t* active) {
+  if (E->cfg.ally_policy != TE_ALLY_EXTERNAL || E->cfg.n_pursuers != 2) return 1;
+  return ote_observe_wingman(E, 1, lidar, inertial, last_action, active);
+}
+OTE_API int ote_set_ally_actions(ote_env* E, const float* actions) {
+  if (E->cfg.ally_policy != TE_ALLY_EXTERNAL || E->cfg.n_pursuers != 2) return 1;
+  return ote_set_wingman_actions(E, 1, actions);
 }
 /* Evaluation_Task.compute_info (evaluation_task.py:553-574): (lw_kills, lw_alive, lw_munitions, current_wave, step) per pursuer */
 OTE_API int ote_wingman_info(const ote_env* E, int32_t* out) {
@@ -1751,8 +1763,9 @@ OTE_API int ote_get_state(const ote_env* E, uint32_t* dst) {
     w[TE_E_DEADS] = (uint32_t)r->deads; w[TE_E_SNAP_MASK] = r->snap_mask; w[TE_E_EPISODE] = (uint32_t)r->episode;
     put_f(w, TE_E_LAST_ACTION, r->last_action, 4); put_f(w, TE_E_PREV_SNAP_MIN, &r->prev_snap_min, 1);
   }
-  if (E->cfg.ally_policy == TE_ALLY_EXTERNAL)  /* the ally policy's last action lives in pursuer 1's TE_D_ALLY_ACTION words */
-    for (int e = 0; e < E->cfg.n_envs; ++e) put_f(dst + ((size_t)e * E->D + 1) * TE_DRONE_WORDS, TE_D_ALLY_ACTION, E->envs[e].ally_action, 4);
+  for (int p = 0; p < E->cfg.n_pursuers; ++p)  /* a caller-driven pursuer keeps its driver's last action in its TE_D_ALLY_ACTION words */
+    if (driven_externally(&E->cfg, p))
+      for (int e = 0; e < E->cfg.n_envs; ++e) put_f(dst + ((size_t)e * E->D + p) * TE_DRONE_WORDS, TE_D_ALLY_ACTION, E->drones[(size_t)e * E->D + p].ext_action, 4);
   if (E->ring) memcpy(base + (size_t)E->cfg.n_envs * TE_ENV_WORDS, E->ring, ring_words(E) * sizeof(uint32_t));
   return 0;
 }
@@ -1783,11 +1796,13 @@ OTE_API int ote_set_state(ote_env* E, const uint32_t* src) {
     r->deads = (int32_t)w[TE_E_DEADS]; r->snap_mask = w[TE_E_SNAP_MASK]; r->episode = (int32_t)w[TE_E_EPISODE];
     get_f(w, TE_E_LAST_ACTION, r->last_action, 4); get_f(w, TE_E_PREV_SNAP_MIN, &r->prev_snap_min, 1);
   }
-  if (E->cfg.ally_policy == TE_ALLY_EXTERNAL)
-    for (int e = 0; e < E->cfg.n_envs; ++e) {
-      get_f(src + ((size_t)e * E->D + 1) * TE_DRONE_WORDS, TE_D_ALLY_ACTION, E->envs[e].ally_action, 4);
-      for (int k = 0; k < 6; ++k) E->drones[(size_t)e * E->D + 1].pending[k] = 0;  /* not a wrench in this layout */
-    }
+  for (int p = 0; p < E->cfg.n_pursuers; ++p)
+    if (driven_externally(&E->cfg, p))
+      for (int e = 0; e < E->cfg.n_envs; ++e) {
+        ote_drone* d = &E->drones[(size_t)e * E->D + p];
+        get_f(src + ((size_t)e * E->D + p) * TE_DRONE_WORDS, TE_D_ALLY_ACTION, d->ext_action, 4);
+        for (int k = 0; k < 6; ++k) d->pending[k] = 0;  /* not a wrench in this layout */
+      }
   if (E->ring) memcpy(E->ring, base + (size_t)E->cfg.n_envs * TE_ENV_WORDS, ring_words(E) * sizeof(uint32_t));
   return 0;
 }

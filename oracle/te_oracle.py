@@ -46,6 +46,8 @@ def lib(precision: str = "f64") -> C.CDLL:
         L.ote_observe_stacked.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.ote_observe_ally.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.ote_set_ally_actions.argtypes = [C.c_void_p, C.c_void_p]
+        L.ote_observe_wingman.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.ote_set_wingman_actions.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ote_wingman_info.argtypes = [C.c_void_p, C.c_void_p]
         L.ote_stack_draws.argtypes = [C.POINTER(K.Config), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
         L.ote_state_margins.argtypes = [C.c_void_p, C.c_void_p]
@@ -145,19 +147,27 @@ class OracleEnv:
         return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
 
     # exp05 ----------------------------------------------------------------------------------
-    def observe_ally(self):
-        """(lidar [N,3,13,26], inertial [N,15], last_action [N,4], active [N] u8) of pursuer 1 on the current state."""
+    def observe_wingman(self, wingman: int):
+        """(lidar [N,3,13,26], inertial [N,15], last_action [N,4], active [N] u8) of a caller-driven pursuer on the current state."""
         lidar, inertial = np.empty_like(self.lidar), np.empty_like(self.inertial)
         last_action, active = np.empty_like(self.last_action), np.empty(self.N, np.uint8)
-        rc = self.L.ote_observe_ally(self.h, _p(lidar), _p(inertial), _p(last_action), _p(active))
-        assert rc == 0, "observe_ally needs cfg.ally_policy == ALLY_EXTERNAL with 2 pursuers"
+        rc = self.L.ote_observe_wingman(self.h, wingman, _p(lidar), _p(inertial), _p(last_action), _p(active))
+        assert rc == 0, "observe_wingman: this pursuer is not driven by the caller"
         return lidar, inertial, last_action, active
 
-    def set_ally_actions(self, actions: np.ndarray):
+    def set_wingman_actions(self, wingman: int, actions: np.ndarray):
         a = np.ascontiguousarray(actions, np.float32)
         assert a.shape == (self.N, 4)
-        rc = self.L.ote_set_ally_actions(self.h, _p(a))
-        assert rc == 0, "set_ally_actions needs cfg.ally_policy == ALLY_EXTERNAL with 2 pursuers"
+        rc = self.L.ote_set_wingman_actions(self.h, wingman, _p(a))
+        assert rc == 0, "set_wingman_actions: this pursuer is not driven by the caller"
+
+    def observe_ally(self):
+        assert self.cfg.ally_policy == K.ALLY_EXTERNAL, "observe_ally needs cfg.ally_policy == ALLY_EXTERNAL with 2 pursuers"
+        return self.observe_wingman(1)
+
+    def set_ally_actions(self, actions: np.ndarray):
+        assert self.cfg.ally_policy == K.ALLY_EXTERNAL, "set_ally_actions needs cfg.ally_policy == ALLY_EXTERNAL with 2 pursuers"
+        self.set_wingman_actions(1, actions)
 
     def wingman_info(self) -> np.ndarray:
         """[N,P,5] i32 rows (lw_kills, lw_alive, lw_munitions, current_wave, step) (Evaluation_Task.compute_info)."""

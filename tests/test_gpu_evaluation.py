@@ -83,11 +83,79 @@ def test_evaluation_environment_surface_and_api_errors():
     assert terminated and latest and max(r["step"] for r in latest.values()) >= steps - 1
     assert sum(r["lw_kills"] for r in latest.values()) >= 1
     env.close()
-    with pytest.raises(ValueError, match="behaviour-tree"):
-        EvaluationEnvironment({"drivers": [{"type": "nn", "path": "model.zip", "name": "nn_1"}]})
     plain = BatchedEnv(default_config("exp03", n_envs=64), "cuda:0")
     with pytest.raises(_lib.TEError, match="cfg.evaluation"):
         plain.wingman_info()
     plain.close()
     with pytest.raises(_lib.TEError, match="Evaluation_Task"):
         BatchedEnv(default_config("evaluation", n_envs=64, stacked_obs=1), "cuda:0")
+
+
+def test_caller_driven_wingmen_parity_and_nn_driver_surface():
+    """cfg.evaluation's driver mask (the reference's "nn" drivers, evaluation_task.py:257-268,655-661): te_observe_wingman /
+    te_set_wingman_actions for pursuers 0 and 1 against the oracle, then EvaluationEnvironment with a model object."""
+    torch = _gpu()
+    from dronechase_amd import _lib, default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    from dronechase_amd.envs import EvaluationEnvironment
+    from oracle import te_oracle as O
+
+    N, P = 4096, 2
+    rounds = int(_lib.load().te_calculate_rounds(P, 20))
+    cfg = default_config("evaluation", n_envs=N, motor_noise=1, seed=29, n_pursuers=P, n_rounds=rounds, n_invaders=rounds,
+                         evaluation=1 | (0b11 << 8))
+    D = cfg.n_drones
+    orc, gpu = O.OracleEnv(cfg, "f32", threads=8), BatchedEnv(cfg, "cuda:0")
+    orc.reset(); gpu.reset()
+    zeros = np.zeros((N, 4), np.float32)
+    step = n_ambiguous = 0
+    for chk in range(6):
+        for _ in range(25):
+            for p in range(P):
+                orc.set_wingman_actions(p, orc.random_actions(50 + p, step))
+            orc.step(zeros); step += 1
+        gpu.set_state(torch.from_numpy(orc.get_state().view(np.int32)).cuda())
+        for p in range(P):
+            ol, oi, oa, oact = orc.observe_wingman(p)
+            gl, gi, ga, gact = (x.cpu().numpy() for x in gpu.observe_wingman(p))
+            np.testing.assert_array_equal(gact, oact); np.testing.assert_array_equal(ga, oa)
+            np.testing.assert_allclose(gi, oi, atol=OBS_TOL)
+            assert (np.abs(gl - ol).reshape(N, -1).max(1) > OBS_TOL).sum() <= max(2, N // 500)
+            act = orc.random_actions(50 + p, step)
+            orc.set_wingman_actions(p, act); gpu.set_wingman_actions(p, torch.from_numpy(act).cuda())
+        orc.step(zeros); gpu.step(torch.from_numpy(zeros).cuda()); step += 1
+        ok = orc.margins() > MARGIN
+        diff, imis = _compare_states(orc.get_state(), gpu.get_state().cpu().numpy().view(np.uint32), N, D)
+        n_ambiguous += int((~ok).sum())
+        assert not (imis & ok).any()
+        assert diff[ok & ~imis].max() < STATE_TOL
+        np.testing.assert_array_equal(gpu.wingman_info().cpu().numpy()[ok & ~imis], orc.wingman_info()[ok & ~imis])
+    assert n_ambiguous <= 6 * N // 50
+    gpu.close(); orc.close()
+    scripted = BatchedEnv(default_config("evaluation", n_envs=64), "cuda:0")
+    with pytest.raises(_lib.TEError, match="not driven by the caller"):
+        scripted.observe_wingman(0)
+    scripted.close()
+    with pytest.raises(_lib.TEError, match="does not exist"):
+        BatchedEnv(default_config("evaluation", n_envs=64, evaluation=1 | (0b10 << 8)), "cuda:0")
+
+    class Model:                      # what PPO.load would return in the reference
+        calls = 0
+
+        def predict(self, observation, deterministic=True):
+            assert deterministic and observation["lidar"].shape == (3, 13, 26) and observation["inertial_data"].shape == (15,)
+            Model.calls += 1
+            return np.array([1.0, 0.0, 0.0, 0.5], np.float32), None
+
+    env = EvaluationEnvironment({"drivers": [{"type": "nn", "name": "nn_1", "model": Model()}, {"type": "bt", "name": "bt_1"}]})
+    assert env.cfg.evaluation == 1 | (0b01 << 8)
+    env.reset(0)
+    for _ in range(5):
+        obs, reward, terminated, truncated, info = env.step(np.zeros(1))
+    assert Model.calls == 5 and set(info) <= {"nn_1", "bt_1"} and reward == 0.0
+    from dronechase_amd import config as K
+    sp = env._b.get_state().view(torch.float32)[: env._b.D * K.DRONE_WORDS].view(env._b.D, K.DRONE_WORDS)[0, K.D["SETPOINT"]:K.D["SETPOINT"] + 4]
+    np.testing.assert_allclose(sp.cpu().numpy(), [0.5, 0.0, 0.0, 0.0], atol=1e-6)     # the model's command, not the behaviour tree's
+    env.close()
+    with pytest.raises(ValueError, match="model"):
+        EvaluationEnvironment({"drivers": [{"type": "nn", "path": "model.zip", "name": "nn_1"}]})

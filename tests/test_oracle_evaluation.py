@@ -1,10 +1,14 @@
 """Evaluation_Task rules (per-wingman info rows; level4/evaluation_environment.py:170-187,
-tasks/evaluation_task.py:89-112,257-275,381-404,498-574) as the config switch cfg.evaluation, behaviour-tree drivers only.
+tasks/evaluation_task.py:89-112,257-275,381-404,498-574) as the config switch cfg.evaluation: behaviour-tree drivers, and
+caller-driven ones (the reference's "nn" drivers) through the driver mask.
 CPU scenario tests of the oracle, each tied to the reference lines it restates; the GPU path is held to the oracle by
 tests/test_gpu_evaluation.py."""
 import numpy as np
+import pytest
+
 from dronechase_amd import config as K
 from oracle import te_oracle as O
+from tests._blob import Blob
 from tests.test_oracle_tasks import arena, load, step
 
 
@@ -113,3 +117,55 @@ def test_free_running_episodes_end_and_rows_are_consistent():
         assert (rows[~live][..., 0] == 0).all() and (rows[~live][..., 4] == 0).all()   # auto-reset: fresh episode
         dones += int(d.sum()); max_kills = max(max_kills, int(rows[..., 0].max())); max_wave = max(max_wave, int(rows[..., 3].max()))
     assert dones > 0 and max_kills >= 2 and max_wave >= 3   # the behaviour tree kills, clears waves, and episodes end
+
+
+def _action_of_setpoint(sp):
+    v = np.array([sp[0], sp[1], sp[3]], np.float64)
+    n = np.linalg.norm(v)
+    return np.array([*(v / n if n > 0 else v), n], np.float32)
+
+
+def test_caller_driven_wingmen_that_answer_like_the_behaviour_tree_reproduce_the_scripted_run():
+    """Evaluation_Task.drive_lw treats a driver with `predict` like exp05's ally (evaluation_task.py:257-268): observation,
+    predict, drive.  cfg.evaluation's driver mask hands those pursuers to the caller (ote_observe_wingman /
+    ote_set_wingman_actions); feeding back the command the behaviour tree gives in the all-scripted twin must give the same run."""
+    N, T, P = 32, 120, 2
+    rounds = O.lib("f64").te_calculate_rounds(P, 20)
+    base = dict(n_envs=N, seed=4, motor_noise=1, n_pursuers=P, n_rounds=rounds, n_invaders=rounds, max_step=60)
+    cs = O.default_config("evaluation", **base)                                   # both wingmen scripted
+    cx = O.default_config("evaluation", evaluation=1 | (0b11 << 8), **base)       # both flown by the caller
+    es, ex = O.OracleEnv(cs, "f64"), O.OracleEnv(cx, "f64")
+    es.reset(); ex.reset()
+    with pytest.raises(AssertionError):
+        es.observe_wingman(0)                     # not caller-driven in the scripted twin
+    zeros = np.zeros((N, 4), np.float32)
+    dones = 0
+    for t in range(T):
+        before = Blob(es.get_state(), N, cs.n_drones)
+        _, _, _, r, d, info = (x.copy() for x in es.step(zeros))
+        after = Blob(es.get_state(), N, cs.n_drones)
+        probe = None
+        for p in range(P):
+            lid, inert, last, active = ex.observe_wingman(p)
+            assert (active == np.array([before.i(e, p, "ARMED") for e in range(N)])).all()
+            acts = np.zeros((N, 4), np.float32)
+            for e in range(N):
+                if not before.i(e, p, "ARMED"):
+                    continue
+                if d[e]:          # auto-reset wiped the set-point: replay the step without auto-reset to read it
+                    if probe is None:
+                        probe = O.OracleEnv(O.default_config("evaluation", auto_reset=0, **base), "f64")
+                        probe.set_state(before.w); probe.step(zeros)
+                        probe = Blob(probe.get_state(), N, cs.n_drones)
+                    acts[e] = _action_of_setpoint(probe.f(e, p, "SETPOINT", 4))
+                else:
+                    acts[e] = _action_of_setpoint(after.f(e, p, "SETPOINT", 4))
+            ex.set_wingman_actions(p, acts)
+        _, _, _, rx, dx, infox = ex.step(zeros)
+        np.testing.assert_array_equal(dx, d); np.testing.assert_array_equal(infox, info)
+        np.testing.assert_array_equal(ex.wingman_info(), es.wingman_info())
+        dones += int(d.sum())
+    assert dones >= 5      # resets happened (every kill extends the time limit by 100 steps: episodes are long)
+    bs, bx = Blob(es.get_state(), N, cs.n_drones), Blob(ex.get_state(), N, cx.n_drones)
+    keep = [i for i in range(K.DRONE_WORDS) if not (K.D["ALLY_ACTION"] <= i < K.D["ALLY_ACTION"] + 4) and i not in K.D_INT_WORDS]
+    np.testing.assert_allclose(bx.dr[..., keep].view(np.float32), bs.dr[..., keep].view(np.float32), atol=1e-5)
