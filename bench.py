@@ -44,7 +44,10 @@ def parse():
     ap.add_argument("--action-seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-profile-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-profile-events", action="store_true", help="do not time the kernels with HIP events (a separate short loop after each window)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the steady-state and all-armed windows")
+    ap.add_argument("--steady-after", type=int, default=1000, help="rollout step at which the steady-state window starts")
+    ap.add_argument("--steady-steps", type=int, default=200)
     return ap.parse_args()
 
 
@@ -175,84 +178,155 @@ def main():
         D = cfg.n_drones
         return float((w[: n_local * D * K.DRONE_WORDS].view(n_local, D, K.DRONE_WORDS)[:, :, K.D["ARMED"]] != 0).float().sum(1).mean().item())
 
+    n_batches = n_total if pregen else 1
+
+    def timed(first: int, count: int) -> float:
+        """Wall time of `count` consecutive steps starting at rollout step `first`, bracketed by barrier + synchronize on both
+        sides, max over ranks.  Nothing but the step's own launches is enqueued in between (no event records)."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(count):
+            one_step((first + i) % n_batches if pregen else first + i)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def kernel_times(first: int, count: int):
+        """Average duration of the two kernels over `count` more steps, from HIP events on the stream te_step launches on
+        (te_profile_begin/end).  A SEPARATE short loop: each event record costs ~3 us of stream time, which the
+        headline loop must not pay."""
+        env.profile_begin(count)
+        for i in range(count):
+            one_step((first + i) % n_batches if pregen else first + i)
+        torch.cuda.synchronize(device)
+        return env.profile_end()
+
+    D = cfg.n_drones
+    per_drone = 2 * 176                                           # sub-step kernel: state read + written per armed drone
+    lidar_bytes = (6 if cfg.stacked_obs else 1) * 3 * 338 * 4     # own sphere, or level5's six stacked spheres
+    alg_all = _lib.algorithmic_bytes_per_env_step(cfg)            # SURVEY.md 8(d): every slot armed (8108 B for stage03)
+    alg_k2 = alg_all - (D * per_drone + 16 + lidar_bytes)         # engage/observe kernel (+ stacked_kernel in level5): the rest
+
+    def priced(armed: float):
+        """Algorithmic bytes of one env-step with `armed` drones flown: only ARMED drones are flown (a disarmed slot costs one
+        scalar flag load), so the drone-state term of SURVEY.md 8(d) is priced at the census, not at all D slots."""
+        k1 = armed * per_drone + 16 + lidar_bytes
+        return k1, k1 + alg_k2
+
+    def regime(first: int, count: int, n_events: int, label: str) -> dict:
+        """One measured regime of the rollout: `count` steps on the wall clock (no events), then `n_events` more steps with the
+        kernels bracketed by HIP events.  Every fraction of the HBM peak is computed from the WALL time of the step."""
+        a0 = armed_per_env() if rank == 0 else 0.0
+        el = timed(first, count)
+        a1 = armed_per_env() if rank == 0 else 0.0
+        k1_ms = k2_ms = 0.0; n_prof = 0
+        if use_events and n_events > 0:
+            k1_ms, k2_ms, n_prof = kernel_times(first + count, n_events)
+        armed = 0.5 * (a0 + a1)
+        ms = 1e3 * el / count
+        b_k1, b_step = priced(armed)
+        out = {"label": label, "first_step": first, "steps": count, "value": world * n_local * count / el, "unit": "env-steps/s",
+               "ms_per_step": ms, "armed_drones_per_env": armed, "armed_drones_per_env_begin_end": [a0, a1],
+               "algorithmic_bytes_per_env_step": b_step,
+               "roofline_env_step": {"bound": "hbm", "achieved": b_step * n_local / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": b_step * n_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "from": "wall-clock ms_per_step"}}
+        if n_prof:
+            out["kernels"] = {"substeps_kernel_ms": k1_ms, "engage_observe_kernel_ms": k2_ms, "launches_timed": n_prof,
+                              "timed_in": "a separate loop of the next steps, HIP events on te_step's stream",
+                              "substeps_kernel_hbm_frac": b_k1 * n_local / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "engage_observe_kernel_hbm_frac": alg_k2 * n_local / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        return out, el, (k1_ms, k2_ms, n_prof, armed)
+
+    use_events = not args.no_profile_events
     env.reset()
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize(device)
-    use_events = not args.no_profile_events
-    n_events = min(args.steps, 64)
-    armed_begin = armed_per_env() if rank == 0 else 0.0
-    if use_events:  # HIP events bracket the two kernels of the first <= 64 timed steps (each record costs ~3 us of stream time)
-        env.profile_begin(n_events)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    k1_ms, k2_ms, n_prof = env.profile_end() if use_events else (0.0, 0.0, 0)
+    # ---- headline: EXACTLY args.steps steps after args.warmup, nothing else in the timed region
+    head, elapsed, (k1_ms, k2_ms, n_prof, armed) = regime(args.warmup, args.steps, min(args.steps, 32), "headline")
     done_frac = float(env.done.float().mean().item())
-    armed_end = armed_per_env() if rank == 0 else 0.0
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    extra = {}
+    if not args.headline_only:
+        # ---- steady state: the rollout gets heavier as episodes progress (more invaders per wave, spread over more slots);
+        # fast-forward to step args.steady_after (untimed), then time args.steady_steps steps the same way
+        pos = args.warmup + args.steps + (min(args.steps, 32) if use_events else 0)
+        for i in range(pos, max(pos, args.steady_after)):
+            one_step(i % n_batches if pregen else i)
+        pos = max(pos, args.steady_after)
+        extra["steady_state"], _, _ = regime(pos, args.steady_steps, 32, f"steady state: steps {pos}..{pos + args.steady_steps} of the same rollout")
+        # ---- every slot armed: the heaviest step the task can ask for (a trained policy in the last waves).  A state blob
+        # with all D drones armed is loaded (te_set_state) and a short window is timed before episodes end and thin it out
+        if int(cfg.task) in (3, 4, 5, 7) and not cfg.stacked_obs and not cfg.evaluation:
+            from dronechase_amd import config as K
+            w = env.get_state().clone()
+            dr = w[: n_local * D * K.DRONE_WORDS].view(n_local, D, K.DRONE_WORDS)
+            er = w[n_local * D * K.DRONE_WORDS: n_local * (D * K.DRONE_WORDS + K.ENV_WORDS)].view(n_local, K.ENV_WORDS)
+            g = torch.Generator(device=device); g.manual_seed(99)
+            # disarmed invaders are put on the born sphere like a new wave would (exp03_vFinal_task.py:584-608), at rest
+            dead = dr[:, :, K.D["ARMED"]] == 0
+            th = torch.rand((n_local, D), device=device, generator=g) * 3.14159265
+            ph = 0.8411 + torch.rand((n_local, D), device=device, generator=g) * (1.5707963 - 0.8411)
+            pos3 = torch.stack((6 * ph.sin() * th.cos(), 6 * ph.sin() * th.sin(), 6 * ph.cos()), -1)
+            fl = dr.view(torch.float32)
+            for k in range(3):
+                fl[:, :, K.D["POS"] + k] = torch.where(dead, pos3[:, :, k], fl[:, :, K.D["POS"] + k])
+                fl[:, :, K.D["OBS_POS"] + k] = torch.where(dead, pos3[:, :, k], fl[:, :, K.D["OBS_POS"] + k])
+            dr[:, :, K.D["ARMED"]] = 1
+            er[:, K.E["ROUND"]] = int(cfg.n_rounds)
+            er[:, K.E["SNAP_MASK"]] = (1 << D) - 1
+            env.set_state(w)
+            extra["all_armed"], _, _ = regime(0, 48, 16, f"every slot armed (round {int(cfg.n_rounds)} state loaded with te_set_state), first 48 steps")
 
     if rank == 0:
-        D = cfg.n_drones
-        total_env_steps = world * n_local * args.steps
-        value = total_env_steps / elapsed
-        alg_all = _lib.algorithmic_bytes_per_env_step(cfg)      # whole env.step with all D drones armed = 8108 B for stage03
-        # Only ARMED drones are flown (a disarmed slot costs one flag load), and in a random-action rollout most invader
-        # slots are empty for the first few hundred steps, so the algorithmic bytes are priced at the armed count that
-        # was actually there: the mean of the census taken right before and right after the timed region, weighted to the
-        # event-timed window (its first n_events steps).  DESIGN.md 4 has the per-term table.
-        frac_window = 0.5 * n_events / max(args.steps, 1)
-        armed = armed_begin + (armed_end - armed_begin) * frac_window
-        per_drone = 2 * 176                                        # sub-step kernel: state read + written per armed drone
-        lidar_bytes = (6 if cfg.stacked_obs else 1) * 3 * 338 * 4     # own sphere, or level5's six stacked spheres
-        alg_k1 = armed * per_drone + 16 + lidar_bytes              # + action + LIDAR background
-        alg_k2 = alg_all - (D * per_drone + 16 + lidar_bytes)      # engage/observe kernel (+ stacked_kernel in level5): the rest
-        alg = alg_k1 + alg_k2
+        value = world * n_local * args.steps / elapsed
+        b_k1, alg = priced(armed)
         out = {
             "metric": "env-steps/sec (whole job), random-action rollout",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.task} (level4 exp03-vFinal shape: {cfg.n_pursuers} pursuers + {cfg.n_invaders} "
-                                   f"invaders, {'stacked-sphere LIDAR 6x3x13x26' if cfg.stacked_obs else 'own-sphere LIDAR 3x13x26'}), {n_local} envs per GPU, 16 physics sub-steps per env-step, "
+                                   f"invader slots, of which {armed:.1f} drones per env are armed (flown) in the timed window; "
+                                   f"{'stacked-sphere LIDAR 6x3x13x26' if cfg.stacked_obs else 'own-sphere LIDAR 3x13x26'}), {n_local} envs per GPU, 16 physics sub-steps per env-step, "
                                    f"random actions, motor noise {'on' if cfg.motor_noise else 'off'}, auto-reset on",
-                       "task": args.task, "envs_per_gpu": n_local, "total_envs": world * n_local, "drones_per_env": D,
-                       "parallelism": f"env-sharded x{world}, no collective"},
+                       "task": args.task, "envs_per_gpu": n_local, "total_envs": world * n_local, "drone_slots_per_env": D,
+                       "armed_drones_per_env": armed, "parallelism": f"env-sharded x{world}, no collective"},
             "done_fraction_last_step": done_frac,
         }
-        if use_events and n_prof:
-            dom_ms, dom_name, dom_bytes = max((k1_ms, "substeps_kernel", alg_k1), (k2_ms, "engage_observe_kernel", alg_k2))
+        if n_prof:
+            dom_ms, dom_name, dom_bytes = max((k1_ms, "substeps_kernel", b_k1), (k2_ms, "engage_observe_kernel", alg_k2))
             ach = dom_bytes * n_local / (dom_ms * 1e-3) / 1e9
-            traffic = None
+            traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc) and args.task in ("stage03", "exp03") and n_local == 65536 and not args.n_invaders:  # what the PMC passes were taken on
                 try:
-                    traffic = json.load(open(pmc)).get(dom_name, {}).get("hbm_bytes_per_launch")
+                    rec = json.load(open(pmc))
+                    traffic = rec.get(dom_name, {}).get("hbm_bytes_per_launch")
+                    traffic_source = f"profiles/pmc_latest.json ({rec.get('source', 'separate rocprofv3 --pmc passes of this command')}): not measured in this run"
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": dom_bytes * n_local, "avg_launch_ms": dom_ms,
-                               "launches_timed": n_prof, "armed_drones_per_env": armed,
+                               "launches_timed": n_prof, "timed_in": "a separate loop of the steps right after the headline window (HIP events on te_step's stream)",
+                               "armed_drones_per_env": armed,
                                "valu_issue_frac_substeps_kernel": (armed * n_local / 64.0) * SUBSTEPS * VALU_CLOCKS_PER_DRONE_SUBSTEP
                                                                   / (SIMDS * CLOCK_HZ * k1_ms * 1e-3),
-                               "armed_drones_per_env_begin_end": [armed_begin, armed_end]}
-            step_ms = k1_ms + k2_ms
-            out["roofline_env_step"] = {"bound": "hbm", "achieved": alg * n_local / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": alg * n_local / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "algorithmic_bytes_per_env_step": alg, "algorithmic_bytes_all_armed": alg_all, "substeps_kernel_ms": k1_ms,
-                                        "engage_observe_kernel_ms": k2_ms}
+                               "armed_drones_per_env_begin_end": head["armed_drones_per_env_begin_end"]}
+        step_ms = 1e3 * elapsed / args.steps
+        out["roofline_env_step"] = {"bound": "hbm", "achieved": alg * n_local / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": alg * n_local / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "from": "wall-clock ms_per_step of the headline window",
+                                    "algorithmic_bytes_per_env_step": alg, "algorithmic_bytes_all_armed": alg_all, "substeps_kernel_ms": k1_ms,
+                                    "engage_observe_kernel_ms": k2_ms}
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.task, overrides, args.action_seed, args.cpu_seconds)

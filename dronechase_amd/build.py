@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libthreatengage.so")
 SOURCES = ["te_env.hip", "te_config.c"]
-DEPS = ["te_env.hip", "te_config.c", "te_device.hpp", os.path.join("..", "..", "include", "threatengage.h")]
+INCLUDE = os.path.join(PKG, "..", "include")
 ARCH = "gfx950"
 
 
@@ -21,33 +21,43 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
 
 
+def deps() -> list:
+    """Every file the library is compiled from: all of csrc/ (te_env.hip includes te_device.hpp, te_logic.hpp,
+    te_stacked.hpp, ...) plus the public headers.  Globbed, so a new header cannot be forgotten."""
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h", ".c", ".cpp"))]
+    out += [os.path.join(INCLUDE, f) for f in sorted(os.listdir(INCLUDE)) if f.endswith(".h")]
+    return out
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps())
 
 
 def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
-    obj = os.path.join(CSRC, "te_config.o")
+    tag = f".{os.getpid()}"  # unique temporaries: two processes building at once each write their own files and the last
+    # os.replace wins with a complete library (never a half-written one)
+    obj = os.path.join(CSRC, f"te_config{tag}.o")
     subprocess.run(["gcc", "-O2", "-fPIC", "-fvisibility=hidden", "-c", os.path.join(CSRC, "te_config.c"), "-o", obj],
                    check=True)
-    hobj = os.path.join(CSRC, "te_env.o")
+    hobj = os.path.join(CSRC, f"te_env{tag}.o")
     # -fno-slp-vectorize: the SLP vectorizer turns the scalar fp32 physics into v_pk_* pairs; on gfx950 that saves
     # no instructions here (the pairs cost as many v_mov to assemble) but needs 95 instead of 72 VGPRs in the
     # sub-step kernel, i.e. 5 instead of 7 waves per SIMD
     compile_cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-gpu-rdc",
                    "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", *extra_flags, "-c", os.path.join(CSRC, "te_env.hip"), "-o", hobj]
-    link_cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", hobj, obj, "-o", LIB + ".tmp", "-lm"]
+    link_cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", hobj, obj, "-o", LIB + tag + ".tmp", "-lm"]
     for cmd in (compile_cmd, link_cmd):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
     os.remove(hobj)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(LIB + tag + ".tmp", LIB)
     os.remove(obj)
     return LIB
 

@@ -740,7 +740,7 @@ struct te_env {
   size_t lds_bytes;
   size_t stack_lds_bytes = 0;  // stacked_kernel (level5)
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
-  uint32_t* ally_scratch = nullptr;  // te_observe_ally: owner planes between its two launches (allocated on first use)
+  uint32_t* ally_scratch = nullptr;  // te_observe_wingman: owner planes between its two launches (te_create allocates them when a wingman is caller-driven)
   int n_fill_waves = 256;  // fill waves of the sub-step kernel: one per CU of an MI355X; four per CU for the six-sphere background of
                            // level5, where ~9 flight waves per SIMD would leave one fill wave too small a share of the issue slots
                            // (605 -> 567 us/step; 512 / 1024 fill waves cost stage03 7 / 40 %); TE_FILL_WAVES overrides
@@ -816,7 +816,13 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (!e) return fail("te_create: out of host memory");
   e->device = device_id;
   e->p.dstate = nullptr; e->p.estate = nullptr; e->p.slot_mask = nullptr; e->p.mixed_count = nullptr; e->p.mixed_items = nullptr; e->p.stage_tab = nullptr; e->p.snap = nullptr; e->p.ring = nullptr; e->p.dbg = nullptr;
+  // ONE failure path from here on: whatever has been allocated so far is released (te_destroy) before the error is returned
   auto bail = [&](const std::string& why) { te_destroy(e); return fail(why); };
+#define TE_HIP_OR_BAIL(x)                                                                              \
+  do {                                                                                                 \
+    hipError_t e_ = (x);                                                                               \
+    if (e_ != hipSuccess) return bail(std::string("te_create: " #x ": ") + hipGetErrorString(e_));      \
+  } while (0)
   e->family = family_of(cfg->task);
   e->p.cfg = *cfg;
   e->p.kd = derive(*cfg);
@@ -848,7 +854,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (hipMalloc(&e->p.slot_mask, (size_t)(e->p.Npad / 64) * 4) != hipSuccess || hipMalloc(&e->p.mixed_count, (size_t)(e->p.Npad / 64) * 4) != hipSuccess ||
       hipMalloc(&e->p.mixed_items, (size_t)(e->p.Npad / 64) * kMixedCap * sizeof(uint16_t)) != hipSuccess)
     return bail("te_create: hipMalloc failed");
-  TE_HIP(hipMemsetAsync(e->p.mixed_count, 0, (size_t)(e->p.Npad / 64) * 4, nullptr));
+  TE_HIP_OR_BAIL(hipMemsetAsync(e->p.mixed_count, 0, (size_t)(e->p.Npad / 64) * 4, nullptr));
   {
     const Rows r{D, cfg->n_pursuers};
     std::vector<uint32_t> tab((size_t)r.staged());
@@ -856,6 +862,11 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     if (hipMalloc(&e->p.stage_tab, tab.size() * 4) != hipSuccess ||
         hipMemcpy(e->p.stage_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
       return bail("te_create: hipMalloc failed");
+  }
+  // caller-driven wingmen (exp05's ally, Evaluation_Task's "nn" drivers): te_observe_wingman's scratch planes are allocated
+  // HERE, not on first use: the entry point only enqueues work (it must be legal under stream capture and never synchronise)
+  if (cfg->ally_policy == TE_ALLY_EXTERNAL || ((uint32_t)cfg->evaluation >> 8) != 0u) {
+    if (hipMalloc(&e->ally_scratch, (size_t)2 * D * e->p.Npad * 4) != hipSuccess) return bail("te_create: hipMalloc failed");
   }
   e->p.entry_words = TE_RING_ENTRY_WORDS(D);
   if (cfg->stacked_obs) {
@@ -865,24 +876,25 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     hipError_t le = hipFuncSetAttribute(reinterpret_cast<const void*>(&stacked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->stack_lds_bytes);
     if (le != hipSuccess || hipMalloc(&e->p.snap, snap_bytes) != hipSuccess || hipMalloc(&e->p.ring, ring_bytes) != hipSuccess)
       return bail("te_create: stacked observation buffers (ring / snapshot / LDS) could not be set up");
-    TE_HIP(hipMemsetAsync(e->p.snap, 0, snap_bytes, nullptr));
-    TE_HIP(hipMemsetAsync(e->p.ring, 0, ring_bytes, nullptr));
+    TE_HIP_OR_BAIL(hipMemsetAsync(e->p.snap, 0, snap_bytes, nullptr));
+    TE_HIP_OR_BAIL(hipMemsetAsync(e->p.ring, 0, ring_bytes, nullptr));
   }
 #ifdef TE_DEBUG_STAMPS
   const size_t dbg_words = 64 + 16 * (size_t)(e->p.Npad / kEPB + 1);
   if (hipMalloc(&e->p.dbg, dbg_words * sizeof(unsigned long long)) != hipSuccess) e->p.dbg = nullptr;
   else { (void)hipMemset(e->p.dbg, 0, dbg_words * sizeof(unsigned long long)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_te_dbg), &e->p.dbg, sizeof(e->p.dbg)); }
 #endif
-  TE_HIP(hipMemsetAsync(e->p.dstate, 0, dwords * 4, nullptr));
-  TE_HIP(hipMemsetAsync(e->p.estate, 0, ewords * 4, nullptr));
+  TE_HIP_OR_BAIL(hipMemsetAsync(e->p.dstate, 0, dwords * 4, nullptr));
+  TE_HIP_OR_BAIL(hipMemsetAsync(e->p.estate, 0, ewords * 4, nullptr));
   hipLaunchKernelGGL(init_planes, dim3(256), dim3(256), 0, nullptr, e->p);
   const int blocks = (e->p.N + 255) / 256;
   launch_by_family(e->family, [&](auto fam) {
     hipLaunchKernelGGL((reset_kernel<decltype(fam)::value>), dim3(blocks), dim3(256), 0, nullptr, e->p, (const uint8_t*)nullptr);
   });
   launch_census(e, nullptr);
-  TE_HIP(hipGetLastError());
-  TE_HIP(hipStreamSynchronize(nullptr));
+  TE_HIP_OR_BAIL(hipGetLastError());
+  TE_HIP_OR_BAIL(hipStreamSynchronize(nullptr));
+#undef TE_HIP_OR_BAIL
   *out = e;
   return 0;
 }
@@ -952,8 +964,7 @@ __attribute__((visibility("default"))) int te_observe_wingman(te_env* e, int32_t
   const size_t n_floats = (size_t)e->p.N * TE_OBS_LIDAR_WORDS;
   const int nchunks = e->p.Npad / kEPB;
   if (ally_lidar && (n_floats & 3) == 0 && (n_floats >> 2) < (1ull << 32) && e->p.N >= 4096) {  // full-size batches: two launches
-    if (!e->ally_scratch && hipMalloc(&e->ally_scratch, (size_t)2 * e->p.D * e->p.Npad * 4) != hipSuccess)
-      return fail("te_observe_wingman: hipMalloc failed");
+    if (!e->ally_scratch) return fail("te_observe_wingman: internal error: no scratch planes (te_create allocates them for caller-driven wingmen)");
     hipLaunchKernelGGL(ally_view_kernel, dim3(256 + nchunks), dim3(64), 0, st, e->p, (int)wingman, ally_lidar, (uint32_t)(n_floats >> 2), 256u,
                        ally_inertial, ally_last_action, ally_active, e->ally_scratch);
     hipLaunchKernelGGL(ally_patch_kernel, dim3((unsigned)(((size_t)e->p.D * e->p.Npad + 255) / 256)), dim3(256), 0, st, e->p, ally_lidar, e->ally_scratch);

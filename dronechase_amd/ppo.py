@@ -135,6 +135,12 @@ class PPO:
     def __init__(self, env, cfg: Optional[PPOConfig] = None, policy: Optional[nn.Module] = None, seed: int = 0):
         self.env, self.cfg = env, cfg or PPOConfig()
         self.device = env.device
+        ecfg = getattr(env, "cfg", None)
+        if ecfg is not None and (int(ecfg.ally_policy) == 3 or (int(ecfg.evaluation) >> 8) != 0):
+            # exp05 / Evaluation_Task "nn" drivers: somebody has to answer te_observe_wingman with te_set_wingman_actions
+            # before every te_step; this rollout loop does not, and the wingman would fly a stale set-point
+            raise ValueError("PPO drives the agent only: an environment with caller-driven wingmen (exp05, evaluation driver mask) "
+                             "needs its wingman driver in the loop (ThreatEngageVecEnv.update_model), not this rollout")
         torch.manual_seed(seed)
         self.policy = (policy or LidarInertialActionPolicy()).to(self.device)
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5)

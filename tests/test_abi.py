@@ -105,3 +105,26 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".c", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "te_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_every_source_of_the_library_is_a_build_dependency(lib):
+    """A logic edit must never leave a stale libthreatengage.so behind (it ships to the GPU box as it is): every file under
+    csrc/ and include/ is a dependency, and touching any of them makes needs_build() true."""
+    from dronechase_amd import build as B
+    names = {os.path.basename(d) for d in B.deps()}
+    assert {"te_env.hip", "te_config.c", "te_device.hpp", "te_logic.hpp", "te_stacked.hpp", "threatengage.h"} <= names
+    # every quoted include of the HIP translation unit is covered
+    for src in ("te_env.hip", "te_logic.hpp", "te_stacked.hpp", "te_device.hpp"):
+        for inc in re.findall(r'#include "([^"]+)"', open(os.path.join(B.CSRC, src)).read()):
+            assert os.path.basename(inc) in names, (src, inc)
+    assert not B.needs_build()
+    lib_mtime = os.path.getmtime(B.LIB)
+    for name in ("te_logic.hpp", "te_stacked.hpp"):
+        path = os.path.join(B.CSRC, name)
+        st = os.stat(path)
+        try:
+            os.utime(path, (lib_mtime + 10, lib_mtime + 10))
+            assert B.needs_build(), name
+        finally:
+            os.utime(path, (st.st_atime, st.st_mtime))
+    assert not B.needs_build()

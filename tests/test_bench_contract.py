@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_keys():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
-                          "--envs-per-gpu", "4096", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
+                          "--envs-per-gpu", "4096", "--cpu-seconds", "1", "--steady-after", "100", "--steady-steps", "20"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -27,5 +27,15 @@ def test_bench_line_has_the_contract_keys():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["avg_launch_ms"] > 0 and "traffic" in r
+    # every regime prices its HBM fraction from its own wall-clock ms_per_step
+    e = d["roofline_env_step"]
+    assert abs(e["frac"] - e["algorithmic_bytes_per_env_step"] * 4096 / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    for name in ("steady_state", "all_armed"):
+        g = d[name]
+        assert g["value"] > 0 and g["steps"] > 0 and abs(g["value"] - 4096 * g["steps"] / (g["ms_per_step"] * 1e-3 * g["steps"])) / g["value"] < 1e-6
+        f = g["roofline_env_step"]
+        assert abs(f["frac"] - g["algorithmic_bytes_per_env_step"] * 4096 / (g["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    assert d["all_armed"]["armed_drones_per_env_begin_end"][0] == 11.0
+    assert d["steady_state"]["first_step"] >= 100
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s" and c["sample"]
