@@ -1,5 +1,5 @@
 # the "other tasks and shard sizes" table of DESIGN.md 4: one bench line per row (200 steps, no CPU baseline)
-row() { python bench.py --steps 200 --no-cpu-baseline "$@" 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); r=d["roofline_env_step"]; print("| %s | %d | %.1f | %.0f M | %.1f | %.1f | %.1f |" % (d["config"]["task"], d["config"]["envs_per_gpu"], d["roofline"]["armed_drones_per_env"], d["value"]/1e6, d["ms_per_step"]*1e3, r["substeps_kernel_ms"]*1e3, r["engage_observe_kernel_ms"]*1e3))'; }
+row() { python bench.py --steps 200 --no-cpu-baseline --headline-only "$@" 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); r=d["roofline_env_step"]; print("| %s | %d | %.1f | %.0f M | %.1f | %.1f | %.1f |" % (d["config"]["task"], d["config"]["envs_per_gpu"], d["roofline"]["armed_drones_per_env"], d["value"]/1e6, d["ms_per_step"]*1e3, r["substeps_kernel_ms"]*1e3, r["engage_observe_kernel_ms"]*1e3))'; }
 row --task stage01 --envs-per-gpu 4096
 row --task stage01 --envs-per-gpu 65536
 row --task stage02 --n-invaders 8 --envs-per-gpu 16384
