@@ -795,7 +795,10 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   const int D = cfg->n_pursuers + cfg->n_invaders;
   if (cfg->n_envs < 1) return fail("te_create: n_envs < 1");
   if (cfg->n_pursuers < 1 || cfg->n_invaders < 1 || D > kMaxD) return fail("te_create: need 1 <= P, 1 <= I, P + I <= 32");
-  if (cfg->substeps < 1 || cfg->substeps > 255) return fail("te_create: substeps out of range");
+  if (cfg->substeps < 0 || cfg->substeps > 255) return fail("te_create: substeps out of range");
+  // substeps == 0: env.step() without physics (the IMU is read from the state as it is, then engagement / reward / termination /
+  // waves / observation as usual).  Used to replay the reference's task-logic fixtures on exactly their positions.
+  if (cfg->substeps == 0 && cfg->observe_lag != 0) return fail("te_create: substeps == 0 (no physics) needs observe_lag == 0");
   if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_EVALUATION) return fail("te_create: unknown task");
   if (cfg->ground_contact && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: cfg.ground_contact is built for the level4 task family only");
   if (cfg->evaluation && (((uint32_t)cfg->evaluation >> 8) >> cfg->n_pursuers) != 0u) return fail("te_create: cfg.evaluation's driver mask names a pursuer that does not exist");

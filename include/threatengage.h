@@ -122,7 +122,8 @@ typedef struct te_config {
   float lidar_radius;     /* 2 * dome_radius */
   float max_speed;        /* 10 km/h = 2.7778 m/s: observation normaliser only (quadcopter.py:590-600) */
 
-  int32_t substeps;       /* physics sub-steps per env.step: 8 sim steps x 2 (level4_simulation.py:84-98) = 16 */
+  int32_t substeps;       /* physics sub-steps per env.step: 8 sim steps x 2 (level4_simulation.py:84-98) = 16.
+                             0 (with observe_lag = 0) = no physics: the step's task logic alone, on the state as loaded */
   float physics_dt;       /* 1/240 */
   float control_dt;       /* 1/120: PID period, although update_control runs every sub-step (reference quirk) */
   int32_t observe_lag;    /* 1: IMU is read before the last integration */

@@ -1,0 +1,67 @@
+"""tests/golden/task_logic.npz (made by tests/golden/gen_task_logic.py from the reference's OffsetHandler, EntitiesManager, Gun and
+Exp03_vFinal_Task) as a state blob, and the comparison of a stepped blob with what the reference produced.
+
+Every arena is one environment at the moment the reference calls `task.on_step_middle()`.  Replay: cfg.substeps = 0 and
+cfg.observe_lag = 0 make env.step() skip the physics (the IMU read after zero sub-steps is the loaded state: identity
+attitude, POS == OBS_POS), so the step's engagement / reward / termination / wave logic runs on exactly the fixture's positions.
+Arena i is env i: the hit draws the reference consumed are the product's Philox words for (seed 0, env i, episode 1, step)."""
+import numpy as np
+
+from dronechase_amd import config as K
+from tests._blob import Blob
+
+
+def config(default_config, g, **extra):
+    n = len(g["step"])
+    return default_config("exp03", n_envs=n, substeps=0, observe_lag=0, motor_noise=0, auto_reset=0, seed=int(g["seed"]),
+                          dome_radius=float(g["dome"]), **extra)
+
+
+def build_blob(g, words: int) -> Blob:
+    n, P, I = len(g["step"]), int(g["P"]), int(g["I"])
+    D = P + I
+    b = Blob(np.zeros(words, np.uint32), n, D)
+    for e in range(n):
+        for s in range(D):
+            b.place(e, s, g["pos"][e, s], armed=int(g["armed"][e, s]))
+            if s < P:
+                b.set_i(e, s, "MUNITION", int(g["munition"][e, s])); b.set_i(e, s, "LAST_FIRED", int(g["last_fired"][e, s]))
+            else:
+                b.set_i(e, s, "MUNITION", 10); b.set_i(e, s, "LAST_FIRED", -60)
+        b.set_f(e, 0, "VEL", g["vel"][e]); b.set_f(e, 0, "OBS_VEL", g["vel"][e])   # identity attitude: body = world
+        b.set_ei(e, "STEP", int(g["step"][e]) - 1)                                 # the step broadcast comes after the sim loop
+        b.set_ei(e, "MAX_STEP", int(g["max_step"][e])); b.set_ei(e, "ROUND", int(g["round"][e]))
+        b.set_ef(e, "LAST_DIST", g["last_dist"][e])
+        b.set_ei(e, "AGENT_KILLS", int(g["kills"][e, 0])); b.set_ei(e, "ALLIES_KILLS", int(g["kills"][e, 1])); b.set_ei(e, "DEADS", int(g["kills"][e, 2]))
+        b.set_ei(e, "EPISODE", int(g["episode"]))
+        b.refresh_snapshot(e)
+    return b
+
+
+def compare(g, reward, done, info, after: Blob, reward_atol=2e-3):
+    """reward / done / info of the step and the state it left, against the reference's numbers.  Returns the number of arenas checked."""
+    n, P, I = len(g["step"]), int(g["P"]), int(g["I"])
+    D = P + I
+    done_ref = g["done"].astype(bool)
+    assert np.array_equal(done.astype(bool), done_ref), np.flatnonzero(done.astype(bool) != done_ref)
+    np.testing.assert_allclose(reward, g["reward"], rtol=2e-6, atol=reward_atol)
+    assert np.array_equal(info, g["info"]), np.flatnonzero((info != g["info"]).any(1))
+    for e in range(n):
+        armed = np.array([after.i(e, s, "ARMED") for s in range(D)])
+        # a terminal step: the reference's on_step_end is unobservable (SB3 resets the env), the product skips it
+        want = g["armed_mid"][e] if done_ref[e] else g["armed_after"][e]
+        assert np.array_equal(armed != 0, want != 0), (e, armed, want)
+        assert [after.i(e, p, "MUNITION") for p in range(P)] == list(g["munition_after"][e]) or not done_ref[e] and g["round_after"][e] != g["round"][e], e
+        fired = g["shots_fired"][e].astype(bool)
+        for p in range(P):
+            if fired[p]:
+                assert after.i(e, p, "LAST_FIRED") == g["step"][e] and after.i(e, p, "MUNITION") == g["munition"][e, p] - 1, (e, p)
+            else:
+                assert after.i(e, p, "LAST_FIRED") == g["last_fired"][e, p] and after.i(e, p, "MUNITION") == g["munition"][e, p], (e, p)
+        assert after.ei(e, "MAX_STEP") == g["max_step_after"][e], e
+        assert [after.ei(e, "AGENT_KILLS"), after.ei(e, "ALLIES_KILLS"), after.ei(e, "DEADS")] == list(g["kills_after"][e]), e
+        np.testing.assert_allclose(after.ef(e, "LAST_DIST")[0], g["last_dist_after"][e], rtol=2e-6, atol=1e-5)
+        if not done_ref[e]:
+            assert after.ei(e, "ROUND") == g["round_after"][e], e
+        assert after.ei(e, "STEP") == g["step"][e], e
+    return n

@@ -1,0 +1,265 @@
+"""The reference-made fixtures of tests/golden/ replayed THROUGH THE C ABI on the GPU and compared with the fixture itself —
+not with the oracle: te_set_state -> te_step / te_observe -> outputs + te_get_state.
+
+  task_logic.npz     OffsetHandler + EntitiesManager + Gun + Exp03_vFinal_Task.on_step_middle / on_step_end on 288 arenas
+  lidar_math.npz     LidarMath binning of 1 000 body-frame vectors; add_features (closer wins) on 50 feature lists
+  gun.npz            Gun traces (can_fire, munition, cooldown, 3-float state)
+  kamikaze.npz       KamikazeNavigator (air-combat-only and cone variants): next state + command
+  normalization.npz  normalize_inertial_data
+
+Steps that must see exactly the fixture's positions run with cfg.substeps = 0, cfg.observe_lag = 0 (no physics: the IMU read is
+the loaded state)."""
+import numpy as np
+import pytest
+
+from dronechase_amd import config as K
+from tests import _task_logic as T
+from tests._blob import Blob
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(cfg):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    from dronechase_amd.batched_env import BatchedEnv
+    return BatchedEnv(cfg, "cuda:0")
+
+
+def _load(env, blob):
+    import torch
+    env.set_state(torch.from_numpy(blob.w.view(np.int32)).cuda())
+
+
+def _state(env, n, D):
+    return Blob(env.get_state().cpu().numpy().view(np.uint32), n, D)
+
+
+def _zeros(n):
+    import torch
+    return torch.zeros((n, 4), dtype=torch.float32, device="cuda:0")
+
+
+def test_task_logic_fixture_through_the_c_abi(golden):
+    from dronechase_amd import default_config
+    g = golden("task_logic.npz")
+    cfg = T.config(default_config, g)
+    env = _gpu(cfg)
+    n = cfg.n_envs
+    _load(env, T.build_blob(g, env.state_words()))
+    _, _, _, reward, done, info = env.step(_zeros(n), terminal=False)
+    checked = T.compare(g, reward.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy(), _state(env, n, cfg.n_drones))
+    assert checked == n >= 200
+    env.close()
+
+
+def _rot_zyx(rpy):
+    cr, sr, cp, sp, cy, sy = np.cos(rpy[0]), np.sin(rpy[0]), np.cos(rpy[1]), np.sin(rpy[1]), np.cos(rpy[2]), np.sin(rpy[2])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]]); Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    return Rz @ Ry @ Rx
+
+
+def _angle_margin(theta, phi):
+    """Distance (rad) of a direction to the nearest LIDAR cell boundary (cells: pi/13 in theta, 2 pi/26 in phi)."""
+    a = (theta / np.pi * 13) % 1.0
+    b = ((phi + np.pi) / (2 * np.pi) * 26) % 1.0
+    return min(a, 1 - a) * np.pi / 13, min(b, 1 - b) * 2 * np.pi / 26
+
+
+def test_lidar_binning_fixture_through_te_observe(golden):
+    """LidarMath.cartesian_to_spherical / theta_index / phi_index / normalize_distance of 1 000 body-frame vectors: each one is
+    the single invader of an env whose agent sits at the origin with identity attitude; the agent's own sphere must hold exactly
+    one hit, in the reference's cell, with the reference's normalised range (none when the range clips to 1.0)."""
+    from dronechase_amd import default_config
+    g = golden("lidar_math.npz")
+    vecs, n = g["vecs"], len(g["vecs"])
+    cfg = default_config("exp02", n_envs=n, n_invaders=1, motor_noise=0, auto_reset=0, lidar_radius=float(g["max_radius"]))
+    env = _gpu(cfg)
+    b = Blob(np.zeros(env.state_words(), np.uint32), n, 2)
+    for e in range(n):
+        b.place(e, 0, (0, 0, 0)); b.place(e, 1, vecs[e]); b.set_ei(e, "STEP", 3); b.refresh_snapshot(e)
+    _load(env, b)
+    lidar = env.observe()[0].cpu().numpy()
+    checked = 0
+    for e in range(n):
+        sph = g["sph"][e]
+        mt, mp = _angle_margin(sph[1], sph[2])
+        rn = float(g["norm_dist"][e])
+        hits = np.argwhere(lidar[e, 0] < 1.0)
+        if rn >= 1.0:
+            if sph[0] > float(g["max_radius"]) * (1 + 1e-6):   # beyond the LIDAR radius: clipped to 1.0 = invisible
+                assert len(hits) == 0, e
+                checked += 1
+            continue
+        # float32 positions: a direction within 1e-5 rad of a cell boundary (or a range of ~0, whose direction is noise) may
+        # legitimately land in the neighbouring cell
+        if min(mt, mp) < 1e-5 or sph[0] < 1e-6:
+            continue
+        assert len(hits) == 1 and tuple(hits[0]) == (int(g["th_idx"][e]), int(g["ph_idx"][e])), (e, hits, g["th_idx"][e], g["ph_idx"][e])
+        t, p = hits[0]
+        assert abs(lidar[e, 0, t, p] - rn) < 1e-6 and abs(lidar[e, 1, t, p] - 0.2) < 1e-7 and abs(lidar[e, 2, t, p] - 0.1) < 1e-7
+        checked += 1
+    assert checked > 950
+    env.close()
+
+
+def test_closer_wins_fixture_through_te_observe(golden):
+    """LidarMath.add_features (closer wins) on the reference's 50 feature lists with forced cell collisions: every feature
+    becomes a drone (LOYALWINGMAN -> a pursuer slot, LOITERINGMUNITION -> an invader slot) at the world position that the
+    agent — at a random position with a random attitude in the second half of the arenas — sees at (r, theta, phi); the
+    agent's own sphere must equal the reference's sphere cell for cell."""
+    from dronechase_amd import default_config
+    g = golden("lidar_math.npz")
+    feats, nf, want = g["feats"], g["n_feats"], g["closer"]
+    n, R = len(nf), float(g["max_radius"])
+    P, I = 12, 11
+    cfg = default_config("exp03", n_envs=n, n_pursuers=P, n_invaders=I, motor_noise=0, auto_reset=0, lidar_radius=R, dome_radius=1000.0)
+    env = _gpu(cfg)
+    D = P + I
+    b = Blob(np.zeros(env.state_words(), np.uint32), n, D)
+    rng = np.random.RandomState(1)
+    risky = np.zeros(n, bool)
+    for e in range(n):
+        rpy = np.zeros(3) if e < n // 2 else rng.uniform([-3, -1.2, -3], [3, 1.2, 3])
+        own = np.zeros(3) if e < n // 2 else rng.uniform(-5, 5, 3)
+        Rm = _rot_zyx(rpy)
+        for s in range(D):
+            b.place(e, s, (500.0 + s, 0, 0), armed=0)
+        b.place(e, 0, own); b.set_f(e, 0, "OBS_EULER", rpy)
+        np_, ni_ = 1, 0
+        for k in range(int(nf[e])):
+            r, th, ph, flag = feats[e, k, :4]
+            # a feature the reference clipped to exactly 1.0 is put slightly beyond the LIDAR radius (any such range clips to
+            # 1.0 and must stay invisible); at exactly R a float32 round trip would decide by its last bit
+            local = (r * R if r < 1.0 else 1.001 * R) * np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)])
+            if abs(flag - 0.6) < 1e-9: s = np_; np_ += 1
+            else: s = P + ni_; ni_ += 1
+            b.place(e, s, own + Rm @ local)
+            mt, mp = _angle_margin(th, ph)
+            risky[e] |= min(mt, mp) < 2e-5 or r * R < 1e-3
+        # two features of one cell at ranges closer than float32 can tell apart would make the winner a coin toss
+        b.set_ei(e, "STEP", 3); b.refresh_snapshot(e)
+    _load(env, b)
+    lidar = env.observe()[0].cpu().numpy()
+    checked = 0
+    for e in range(n):
+        if risky[e]:
+            continue
+        assert np.array_equal(lidar[e, 0] < 1.0, want[e, 0] < 1.0), e                 # the same cells are hit
+        np.testing.assert_allclose(lidar[e], want[e], atol=2e-6, err_msg=str(e))      # range, flag, time planes
+        checked += 1
+    assert checked >= 40
+    assert sum(int(nf[e]) - int((want[e, 0] < 1.0).sum()) for e in range(n) if not risky[e]) >= 20   # collisions were resolved
+    env.close()
+
+
+def test_gun_fixture_through_the_c_abi(golden):
+    """Gun traces (gun.py:56-113 run by gen_golden.py): every row (broadcast step, shoot?, draw) is one env whose agent has the
+    gun state the trace had before that row and, when the row shoots, an invader 0.5 m away.  After one step without physics the
+    munition, the cooldown stamp, the target's fate and the 3-float gun state of the observation must be the reference's.  The
+    Bernoulli draw itself is an input of the trace: rows whose draw hit run with hit_prob 1, the others with 0."""
+    from dronechase_amd import default_config
+    g = golden("gun.npz")
+    assert float(g["cooldown"]) == 60.0 and abs(float(g["hit_prob"]) - 0.9) < 1e-12
+    total = 0
+    for munition in (0, 1, 4, 20):
+        steps, shoot, draws = g[f"steps_{munition}"], g[f"shoot_{munition}"], g[f"draws_{munition}"]
+        hit, mun, state = g[f"hit_{munition}"], g[f"mun_{munition}"], g[f"state_{munition}"]
+        n = len(steps)
+        mun_before = np.concatenate([[munition], mun[:-1]])
+        fired = mun < mun_before
+        last_fired = np.full(n, -60, np.int64)
+        lf = -60
+        for i in range(n):
+            last_fired[i] = lf
+            if fired[i]:
+                lf = int(steps[i])
+        for want_hit in (1, 0):
+            rows = np.flatnonzero((draws < 0.9) == bool(want_hit))
+            cfg = default_config("exp02", n_envs=len(rows), n_invaders=1, munition=munition, hit_prob=float(want_hit), substeps=0, observe_lag=0,
+                                 motor_noise=0, auto_reset=0, n_rounds=1)
+            env = _gpu(cfg)
+            b = Blob(np.zeros(env.state_words(), np.uint32), len(rows), 2)
+            for e, i in enumerate(rows):
+                b.place(e, 0, (0, 0, 3)); b.place(e, 1, (0.5, 0, 3) if shoot[i] else (3, 3, 3))
+                b.set_i(e, 0, "MUNITION", int(mun_before[i])); b.set_i(e, 0, "LAST_FIRED", int(last_fired[i]))
+                b.set_ei(e, "STEP", int(steps[i]) - 1); b.set_ei(e, "MAX_STEP", 10 ** 6); b.set_ei(e, "ROUND", 1); b.set_ei(e, "EPISODE", 1)
+                b.refresh_snapshot(e)
+            _load(env, b)
+            _, inertial, _, _, _, info = env.step(_zeros(len(rows)), terminal=False)
+            inertial, info = inertial.cpu().numpy(), info.cpu().numpy()
+            after = _state(env, len(rows), 2)
+            for e, i in enumerate(rows):
+                assert after.i(e, 0, "MUNITION") == mun[i], (munition, i)
+                assert after.i(e, 0, "LAST_FIRED") == (steps[i] if fired[i] else last_fired[i]), (munition, i)
+                assert (after.i(e, 1, "ARMED") == 0) == bool(hit[i]), (munition, i)
+                assert info[e, 0] == int(hit[i])
+                np.testing.assert_allclose(inertial[e, 12:15], state[i], atol=1e-6, err_msg=f"{munition} {i}")
+            total += len(rows)
+            env.close()
+    assert total == 800
+
+
+@pytest.mark.parametrize("variant", ["aco", "general"])
+def test_kamikaze_fixture_through_the_c_abi(golden, variant):
+    """KamikazeNavigator traces (both variants, run by gen_golden.py with stub offsets): every time step is one env with the
+    trace's positions, armed mask and FSM states; the sub-step kernel's navigator must leave the reference's next state and the
+    velocity set-point of the reference's drive() command."""
+    from dronechase_amd import default_config
+    g = golden("kamikaze.npz")
+    P, I = int(g["P"]), int(g["I"])
+    pos, mask, st_in, st_out, cmd = (g[f"{variant}_{k}"] for k in ("pos", "mask", "state_in", "state_out", "cmd"))
+    n, D = len(mask), P + I
+    import ctypes
+    bp = (ctypes.c_float * 3)(*[float(x) for x in g[f"{variant}_building"]])
+    cfg = default_config("exp03", n_envs=n, n_invaders=I, substeps=0, observe_lag=0, motor_noise=0, auto_reset=0,
+                         kamikaze_cone_check=int(variant == "general"), invader_speed=float(g[f"{variant}_speed"]), building_position=bp,
+                         shoot_range=0.0, explosion_range=0.0, origin_range=0.0, dome_radius=1000.0, max_step=10 ** 6)
+    env = _gpu(cfg)
+    b = Blob(np.zeros(env.state_words(), np.uint32), n, D)
+    for e in range(n):
+        for s in range(D):
+            b.place(e, s, pos[e, s], armed=int((int(mask[e]) >> s) & 1))
+            if s >= P:
+                b.set_i(e, s, "NAV_STATE", int(st_in[e, s]))
+        b.set_ei(e, "STEP", 5); b.set_ei(e, "MAX_STEP", 10 ** 6); b.set_ei(e, "ROUND", I); b.set_ei(e, "EPISODE", 1)
+        b.refresh_snapshot(e)
+    _load(env, b)
+    env.step(_zeros(n), terminal=False)
+    after = _state(env, n, D)
+    checked = 0
+    for e in range(n):
+        for s in range(P, D):
+            if not (int(mask[e]) >> s) & 1:
+                continue
+            assert after.i(e, s, "ARMED") == 1
+            assert after.i(e, s, "NAV_STATE") == st_out[e, s], (e, s)
+            d = cmd[e, s, :3]
+            nrm = np.linalg.norm(d)
+            v = cmd[e, s, 3] * d / (nrm if nrm > 0 else 1.0)
+            np.testing.assert_allclose(after.f(e, s, "SETPOINT", 4), [v[0], v[1], 0.0, v[2]], atol=1e-6, err_msg=f"{e} {s}")
+            checked += 1
+    assert checked > 100
+    env.close()
+
+
+def test_normalization_fixture_through_te_observe(golden):
+    """normalize_inertial_data (level4/components/utils/normalization.py) on 200 states incl. saturating ones: the agent's IMU
+    words are loaded as they are and te_observe must return the reference's 12 floats."""
+    from dronechase_amd import default_config
+    g = golden("normalization.npz")
+    n = len(g["pos"])
+    cfg = default_config("exp02", n_envs=n, n_invaders=1, motor_noise=0, auto_reset=0, dome_radius=float(g["dome_radius"]), max_speed=float(g["max_speed"]))
+    env = _gpu(cfg)
+    b = Blob(np.zeros(env.state_words(), np.uint32), n, 2)
+    for e in range(n):
+        b.place(e, 0, (0, 0, 0)); b.place(e, 1, (3, 3, 3))
+        b.set_f(e, 0, "OBS_POS", g["pos"][e]); b.set_f(e, 0, "OBS_VEL", g["vel"][e]); b.set_f(e, 0, "OBS_EULER", g["att"][e]); b.set_f(e, 0, "OBS_RATE", g["rate"][e])
+        b.set_i(e, 0, "MUNITION", 20); b.set_i(e, 0, "LAST_FIRED", -60); b.set_ei(e, "STEP", 3); b.refresh_snapshot(e)
+    _load(env, b)
+    inertial = env.observe()[1].cpu().numpy()
+    np.testing.assert_allclose(inertial[:, :12], g["out"], atol=1e-6)
+    np.testing.assert_allclose(inertial[:, 12:15], np.tile([1.0, 0.0, 1.0], (n, 1)), atol=0)   # Gun().get_state() == [1, 0, 1]
+    env.close()
