@@ -32,6 +32,10 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m dronechase_amd.build` (needs hipcc, gfx950). "
             "dronechase_amd has no CPU or PyTorch fallback.")
+    # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same soname as /opt/rocm's).  Loaded after torch,
+    # libthreatengage.so binds to the copy torch already mapped and shares its device context; loaded BEFORE torch, it would pull
+    # in /opt/rocm's copy, torch would then bring its own, and the first runtime reports "no ROCm-capable device" at te_create.
+    import torch  # noqa: F401  (device memory / streams plumbing of every caller anyway)
     L = C.CDLL(LIB_PATH)
     vp, i32, u64 = C.c_void_p, C.c_int32, C.c_uint64
     L.te_last_error.restype = C.c_char_p
