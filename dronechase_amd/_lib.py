@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libthreaten
 EXPORTS = (
     "te_config_default", "te_create", "te_destroy", "te_reset", "te_observe", "te_step", "te_random_actions",
     "te_state_words", "te_get_state", "te_set_state", "te_algorithmic_bytes_per_env_step", "te_profile_begin",
-    "te_profile_end", "te_debug_stamps", "te_abi_version", "te_last_error", "te_step_stacked", "te_observe_stacked", "te_observe_ally", "te_set_ally_actions", "te_wingman_info", "te_calculate_rounds", "te_observe_wingman", "te_set_wingman_actions",
+    "te_profile_end", "te_debug_stamps", "te_abi_version", "te_last_error", "te_step_stacked", "te_observe_stacked", "te_observe_ally", "te_set_ally_actions", "te_wingman_info", "te_calculate_rounds", "te_observe_wingman", "te_set_wingman_actions", "te_quad_preset",
 )
 
 
@@ -41,6 +41,7 @@ def load() -> C.CDLL:
     L.te_last_error.restype = C.c_char_p
     L.te_abi_version.restype = C.c_int
     L.te_config_default.argtypes = [C.POINTER(K.Config), i32]
+    L.te_quad_preset.argtypes = [C.POINTER(K.Config), i32]
     L.te_create.argtypes = [C.POINTER(K.Config), i32, C.POINTER(vp)]
     L.te_destroy.argtypes = [vp]
     L.te_destroy.restype = None
@@ -75,12 +76,16 @@ def check(rc: int, what: str = "") -> None:
 
 
 def default_config(task, **overrides) -> K.Config:
-    """te_config_default(task) with keyword overrides (`quad__mass=...` reaches into te_quad_params)."""
+    """te_config_default(task) with keyword overrides (`quad__mass=...` reaches into te_quad_params; `quad_preset=1` swaps the
+    whole quadrotor table with te_quad_preset before the other overrides apply)."""
     t = K.TASKS[task] if isinstance(task, str) else int(task)
     cfg = K.Config()
     rc = load().te_config_default(C.byref(cfg), t)
     if rc:
         raise ValueError(f"unknown task {task!r}")
+    if "quad_preset" in overrides:
+        if load().te_quad_preset(C.byref(cfg), int(overrides.pop("quad_preset"))):
+            raise ValueError("unknown quad_preset")
     return K.apply_overrides(cfg, **overrides)
 
 

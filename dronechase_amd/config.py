@@ -7,12 +7,14 @@ from __future__ import annotations
 
 import ctypes as C
 
-TE_ABI_VERSION = 3
+TE_ABI_VERSION = 4
 
 TASK_STAGE01, TASK_STAGE02, TASK_EXP02, TASK_EXP03, TASK_EXP04, TASK_LEVEL5, TASK_EXP05, TASK_EVALUATION = 1, 2, 3, 4, 5, 6, 7, 8
 TASKS = {"stage01": TASK_STAGE01, "stage02": TASK_STAGE02, "exp02": TASK_EXP02, "exp03": TASK_EXP03,
          "stage03": TASK_EXP03, "exp04": TASK_EXP04, "level5": TASK_LEVEL5, "exp05": TASK_EXP05, "evaluation": TASK_EVALUATION}
 ALLY_NONE, ALLY_BT, ALLY_FROZEN, ALLY_EXTERNAL = 0, 1, 2, 3
+IO_DEVICE, IO_HOST = 0, 1
+QUAD_CF2X_RECALLED, QUAD_CF2X_RECORDED_FIT = 0, 1
 
 LIDAR_NTHETA, LIDAR_NPHI, LIDAR_CHANNELS = 13, 26, 3
 LIDAR_CELLS = LIDAR_NTHETA * LIDAR_NPHI
@@ -74,6 +76,8 @@ class Config(C.Structure):
         ("catch_distance", C.c_float), ("building_position", C.c_float * 3),
         ("motor_noise", C.c_int32), ("auto_reset", C.c_int32), ("kamikaze_cone_check", C.c_int32), ("stacked_obs", C.c_int32),
         ("evaluation", C.c_int32), ("ground_contact", C.c_int32), ("ground_z", C.c_float), ("hull_half_height", C.c_float),
+        ("control_every_substep", C.c_int32), ("lidar_channels", C.c_int32), ("io_location", C.c_int32),
+        ("drone_contact", C.c_int32), ("contact_radius", C.c_float), ("quad_preset", C.c_int32),
         ("quad", QuadParams),
     ]
 

@@ -809,6 +809,10 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->stacked_obs && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: stacked_obs needs a level4-family task");
   if (cfg->task == TE_TASK_STAGE01 && !(cfg->n_pursuers == 2 && cfg->n_invaders == 1)) return fail("te_create: stage01 is 2 pursuers + 1 invader");
   if (cfg->lidar_radius <= 0.0f || cfg->dome_radius <= 0.0f || cfg->max_speed <= 0.0f) return fail("te_create: radii / max_speed must be positive");
+  if (cfg->control_every_substep != 1) return fail("te_create: control_every_substep = 0 is not built yet");
+  if (cfg->lidar_channels != TE_LIDAR_CHANNELS) return fail("te_create: lidar_channels must be 3 (2 is not built yet)");
+  if (cfg->io_location != TE_IO_DEVICE) return fail("te_create: io_location = TE_IO_HOST is not built yet");
+  if (cfg->drone_contact != 0) return fail("te_create: drone_contact is not built yet");
   int ndev = 0;
   TE_HIP(hipGetDeviceCount(&ndev));
   if (ndev < 1) return fail("te_create: no HIP device visible; this library has no CPU fallback");

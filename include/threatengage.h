@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TE_ABI_VERSION 3
+#define TE_ABI_VERSION 4
 
 /* ---- tasks (reference env class each one mirrors) ----------------------- */
 enum {
@@ -163,8 +163,35 @@ typedef struct te_config {
   float ground_z;         /* -6 */
   float hull_half_height; /* 0.0125: half of the cf2x collision cylinder's height (unverified) */
 
+  /* ---- SURVEY.md Appendix A.7 switches (ABI 4) ---- */
+  int32_t control_every_substep; /* 1 (every preset): QuadX.update_control runs on EVERY physics sub-step, as the reference's
+                             simulation loop calls it (level4_simulation.py:92-94), with the PID period still control_dt;
+                             0: PyFlyt-native, update_control on every (physics_hz / ctrl_hz)-th sub-step only (120 Hz), the
+                             motors keep the last pwm in between */
+  int32_t lidar_channels; /* 3 (distance, flag, time: FusedLIDAR own sphere); 2 = the legacy LIDAR's layout
+                             (distance, flag) that the level2-4 docs and the level5 teacher space quote
+                             (sensors/lidar.py:137-145, level5_envrionment.py:79-84): obs_lidar is [N,2,13,26] */
+  int32_t io_location;    /* TE_IO_DEVICE (0): every I/O pointer is a device pointer.  TE_IO_HOST (1): the actions, observation,
+                             reward, done, info and terminal pointers of te_step / te_observe and te_reset's mask are HOST
+                             pointers (what a SubprocVecEnv caller holds); the library stages them through device buffers of
+                             its own with hipMemcpyAsync on the call's stream and the call returns when they have landed */
+  int32_t drone_contact;  /* 1: drone-drone contact (OPT-IN, off in every preset; parity unpinned): armed drones collide as
+                             spheres of contact_radius (Bullet narrow phase with the cf2x collision shapes; group/mask 1/1
+                             for armed drones only, quadcopter.py:484-496): inelastic impulse along the line of centres at
+                             the end of each sub-step, equal masses, no friction, no contact torque */
+  float contact_radius;   /* 0.06: radius of the cf2x collision cylinder (unverified) */
+  int32_t quad_preset;    /* which table te_config_default / te_quad_preset filled `quad` with: TE_QUAD_CF2X_RECALLED (0) or
+                             TE_QUAD_CF2X_RECORDED_FIT (1).  Informational: the kernels read `quad` only */
+
   te_quad_params quad;
 } te_config;
+
+enum { TE_IO_DEVICE = 0, TE_IO_HOST = 1 };
+/* quadrotor parameter presets (te_quad_preset).  RECALLED = PyFlyt 0.11.1's cf2x.yaml / cf2x.urdf as recorded in SURVEY.md
+ * Appendix B (the default of every task); RECORDED_FIT = the same table with the smallest change that reproduces the only
+ * PyBullet-made numbers in the reference tree (io_data0.h5: seven wingmen, two steps after a respawn) within its motor-noise
+ * scatter — see DESIGN.md 5 and tools/physics_fit.py.  Neither is verified against the PyFlyt sources. */
+enum { TE_QUAD_CF2X_RECALLED = 0, TE_QUAD_CF2X_RECORDED_FIT = 1 };
 
 /* ---- state blob (te_get_state / te_set_state) ----------------------------
  * Env-major array of 4-byte words: for env e,
@@ -225,6 +252,9 @@ typedef struct te_env te_env; /* opaque */
  * Mirrors Task.init_constants (exp03_vFinal_task.py:88-112, level3/components/stages.py:65-83,
  * level2/pyflyt_level2_environment_modified_v2.py:27-47). */
 int te_config_default(te_config* cfg, int32_t task);
+
+/* Overwrite cfg->quad (and cfg->quad_preset) with one of the TE_QUAD_* tables. */
+int te_quad_preset(te_config* cfg, int32_t preset);
 
 /* Task.calculate_rounds (exp03_vFinal_task.py:198-226): the number of waves (= invader slots) `defenders` pursuers with
  * `munition` rounds each can clear; what te_config_default puts into n_rounds / n_invaders. */

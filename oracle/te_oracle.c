@@ -50,6 +50,8 @@ typedef struct {
   real obs_pos[3], obs_euler[3], obs_vel[3], obs_rate[3];
   real formation[3];
   real pending[6];
+  real pwm[4]; /* QuadX.pwm: the last update_control's output, what update_physics feeds the motors (only read back when
+                  cfg.control_every_substep == 0; every env.step starts with a control update, so it is not part of the blob) */
   real ext_action[4]; /* caller-driven pursuer: the driver's last action (exp05_vFinal_task.py:139,259; evaluation_task.py:266); blob: TE_D_ALLY_ACTION */
   int32_t armed, munition, last_fired, nav_state;
 } ote_drone;
@@ -389,11 +391,15 @@ static void motor_noise(const ote_env* E, int e, int slot, uint32_t step_index, 
  * (level4_simulation.py:87-98): update_imu -> update_control -> update_physics -> stepSimulation */
 static void substep(const ote_env* E, int e, int slot, ote_drone* d, int mode, uint32_t step_index, int sub) {
   const te_config* c = &E->cfg;
-  real pwm[4], nz[4], Fb[3], Tb[3], Fw[3], Tw[3], m[9];
+  real nz[4], Fb[3], Tb[3], Fw[3], Tw[3], m[9];
   observe(d);
-  control(c, d, mode, pwm);
+  /* the reference's loop calls update_control on every physics sub-step (level4_simulation.py:92-94); PyFlyt's own Aviary
+   * calls it on every (physics_hz / ctrl_hz)-th one (cfg.control_every_substep == 0) and the motors keep the last pwm */
+  int ratio = (int)((real)c->control_dt / (real)c->physics_dt + (real)0.5);
+  if (ratio < 1) ratio = 1;
+  if (c->control_every_substep || sub % ratio == 0) control(c, d, mode, d->pwm);
   motor_noise(E, e, slot, step_index, sub, nz);
-  actuate(c, d, pwm, nz, Fb, Tb);
+  actuate(c, d, d->pwm, nz, Fb, Tb);
   quat_to_mat(d->quat, m);
   mat_vec(m, Fb, Fw);
   mat_vec(m, Tb, Tw);
@@ -1820,6 +1826,35 @@ OTE_API int ote_fly_from(const te_config* cfg, int mode, const double* setpoint,
   for (int k = 0; k < 4; ++k) d.setpoint[k] = (real)setpoint[k];
   for (int s = 0; s < n_substeps; ++s) {
     substep(&E, 0, 0, &d, mode, 0, s);   /* observe() at its top leaves the IMU read of the state BEFORE this integration */
+    for (int k = 0; k < 3; ++k) {
+      out_pos[3 * s + k] = (double)d.obs_pos[k]; out_vel_body[3 * s + k] = (double)d.obs_vel[k];
+      out_euler[3 * s + k] = (double)d.obs_euler[k]; out_rate_body[3 * s + k] = (double)d.obs_rate[k];
+    }
+  }
+  return 0;
+}
+/* The general form for tools/physics_fit.py: set-point schedule (set-point k applies from sub-step sp_start[k] on), the hidden
+ * controller / motor state at release (hidden[16] = zv_i, zv_e, lv_i[2], lv_e[2], av_i[3], av_e[3], throttle[4]), optional
+ * motor noise (noise_env >= 0: the Philox stream of that env index under cfg->seed).  Sub-step s belongs to env-step s / 16. */
+OTE_API int ote_fly_hidden(const te_config* cfg, int mode, const double* setpoints, const int32_t* sp_start, int n_sp, int n_substeps,
+                           const double* pos0, const double* hidden, int noise_env, double* out_pos, double* out_vel_body,
+                           double* out_euler, double* out_rate_body) {
+  ote_env E; memset(&E, 0, sizeof E);
+  ote_envrec er; memset(&er, 0, sizeof er);
+  E.cfg = *cfg; E.cfg.motor_noise = noise_env >= 0; E.D = 1; E.envs = &er;
+  E.cfg.env_index_base = noise_env >= 0 ? noise_env : 0;
+  ote_drone d; memset(&d, 0, sizeof d);
+  d.quat[3] = 1; d.armed = 1;
+  d.zv_i = (real)hidden[0]; d.zv_e = (real)hidden[1];
+  for (int k = 0; k < 2; ++k) { d.lv_i[k] = (real)hidden[2 + k]; d.lv_e[k] = (real)hidden[4 + k]; }
+  for (int k = 0; k < 3; ++k) { d.av_i[k] = (real)hidden[6 + k]; d.av_e[k] = (real)hidden[9 + k]; }
+  for (int k = 0; k < 4; ++k) d.throttle[k] = (real)hidden[12 + k];
+  for (int k = 0; k < 3; ++k) d.pos[k] = (real)pos0[k];
+  int cur = -1;
+  const int per_step = cfg->substeps > 0 ? cfg->substeps : 16;
+  for (int s = 0; s < n_substeps; ++s) {
+    while (cur + 1 < n_sp && sp_start[cur + 1] <= s) { ++cur; for (int k = 0; k < 4; ++k) d.setpoint[k] = (real)setpoints[4 * cur + k]; }
+    substep(&E, 0, 0, &d, mode, (uint32_t)(s / per_step), s % per_step);
     for (int k = 0; k < 3; ++k) {
       out_pos[3 * s + k] = (double)d.obs_pos[k]; out_vel_body[3 * s + k] = (double)d.obs_vel[k];
       out_euler[3 * s + k] = (double)d.obs_euler[k]; out_rate_body[3 * s + k] = (double)d.obs_rate[k];

@@ -53,6 +53,7 @@ def lib(precision: str = "f64") -> C.CDLL:
         L.ote_state_margins.argtypes = [C.c_void_p, C.c_void_p]
         L.ote_random_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
         L.te_config_default.argtypes = [C.POINTER(K.Config), C.c_int32]
+        L.te_quad_preset.argtypes = [C.POINTER(K.Config), C.c_int32]
         L.ote_degrees_between.restype = C.c_double
         L.ote_normalize_distance.restype = C.c_double
         L.ote_normalize_distance.argtypes = [C.c_double, C.c_double]
@@ -68,6 +69,9 @@ def default_config(task, **overrides) -> K.Config:
     rc = lib("f64").te_config_default(C.byref(cfg), t)
     if rc:
         raise ValueError(f"te_config_default({task}) -> {rc}")
+    if "quad_preset" in overrides:
+        if lib("f64").te_quad_preset(C.byref(cfg), int(overrides.pop("quad_preset"))):
+            raise ValueError("unknown quad_preset")
     return K.apply_overrides(cfg, **overrides)
 
 
@@ -348,6 +352,17 @@ def fly_from(cfg, mode, setpoint, n_substeps, pos0, zv_i0, precision="f64"):
     sp, p0 = _d(setpoint), _d(pos0)
     out = [np.zeros((n_substeps, 3)) for _ in range(4)]
     lib(precision).ote_fly_from(C.byref(cfg), C.c_int(mode), _p(sp), C.c_int(n_substeps), _p(p0), C.c_double(zv_i0), *[_p(o) for o in out])
+    return out
+
+
+def fly_hidden(cfg, mode, setpoints, sp_start, n_substeps, pos0, hidden, noise_env=-1, precision="f64"):
+    """The general form of fly_from: set-point schedule, hidden controller / motor state at release, optional motor noise.
+    Returns the IMU reads (position, body velocity, euler, body rates) at the top of each sub-step."""
+    sp = _d(setpoints).reshape(-1, 4); st = np.ascontiguousarray(sp_start, np.int32); p0 = _d(pos0); h = _d(hidden)
+    assert h.size == 16 and len(st) == len(sp)
+    out = [np.zeros((n_substeps, 3)) for _ in range(4)]
+    lib(precision).ote_fly_hidden(C.byref(cfg), C.c_int(mode), _p(sp), _p(st), C.c_int(len(sp)), C.c_int(n_substeps), _p(p0), _p(h),
+                                  C.c_int(noise_env), *[_p(o) for o in out])
     return out
 
 

@@ -124,41 +124,76 @@ def test_f32_build_tracks_f64():
     assert np.abs(p64 - p32).max() < 2e-4 and np.abs(v64 - v32).max() < 2e-4
 
 
-def test_recorded_first_steps_weakly_constrain_the_physics():
+def _fit_module():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("physics_fit", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "physics_fit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_recorded_first_steps_against_the_two_quadrotor_presets():
     """tests/golden/ref_level5_obs.npz holds the IMU reads of seven wingmen at two consecutive env-steps right after a
     (re)spawn, each flying a constant BT command of 0.6 m/s (io_data0.h5, the only PyBullet + PyFlyt output in the
-    reference tree).  The hidden controller state at that moment is not recorded (PID memories survive a respawn,
-    quadcopter.py:433-478, so the z-velocity integrator sits near its hover value) and neither package can be run here,
-    so this is NOT a parity test: it pins signs and orders of magnitude of the restated cascade (lin-vel -> tilt ->
-    rate -> torque, z-vel -> thrust, motor lag) against real data.  Measured ratios recorded / restated: tilt 2.1-3.1x
-    after one step and 1.3-1.9x after two, body rates 1.2-2.1x, horizontal speed 2.1-3.8x: the real attitude loop is
-    faster than the UNVERIFIED cf2x table makes it."""
-    import os
-    from oracle import te_oracle as O
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_level5_obs.npz"))
-    I, A = g["inertial"].astype(np.float64), g["last_action"].astype(np.float64)
-    vel, eul, rate = I[:, 3:6] * (10 / 3.6), I[:, 6:9] * np.pi, I[:, 9:12] * 2 * np.pi
-    cfg = O.default_config("level5", n_envs=1)
-    q = cfg.quad
-    hover = float(np.sqrt(q.mass * q.gravity / q.total_thrust))
-    ratios = {"tilt1": [], "tilt2": [], "rate1": [], "speed1": []}
-    for w in range(7):
-        d = A[w, :3] / np.linalg.norm(A[w, :3])
-        assert abs(A[w, 3] - 0.6) < 1e-6
-        p, v, e, r = O.fly_from(cfg, 6, [0.6 * d[0], 0.6 * d[1], 0.0, 0.6 * d[2]], 32, [0, 0, 0], hover)
-        for step, (k, rec) in enumerate(((15, w), (31, w + 7)), start=1):
-            # the command's horizontal direction shows up with the right signs: roll = -y, pitch = +x (PX4 convention)
-            for axis in (0, 1):
-                if abs(eul[rec, axis]) > 0.01:
-                    assert np.sign(e[k, axis]) == np.sign(eul[rec, axis]), (w, step, axis)
-                if abs(vel[rec, axis]) > 0.005:
-                    assert np.sign(v[k, axis]) == np.sign(vel[rec, axis]), (w, step, axis)
-            tilt_rec, tilt_sim = np.hypot(*eul[rec, :2]), np.hypot(*e[k, :2])
-            ratios[f"tilt{step}"].append(tilt_rec / tilt_sim)
-            assert abs(eul[rec, 2]) < 0.01 and abs(e[k, 2]) < 0.01          # no yaw command, no yaw
-            assert abs(v[k, 2]) < 0.3 and abs(vel[rec, 2]) < 0.3            # near hover thrust from the first sub-steps
-        ratios["rate1"].append(np.hypot(*rate[w, :2]) / np.hypot(*r[15, :2]))
-        ratios["speed1"].append(np.hypot(*vel[w, :2]) / np.hypot(*v[15, :2]))
-    for name, (lo, hi) in {"tilt1": (1.5, 4.0), "tilt2": (1.0, 2.5), "rate1": (1.0, 3.0), "speed1": (1.5, 5.0)}.items():
-        x = np.array(ratios[name])
-        assert lo < x.min() and x.max() < hi, (name, x)
+    reference tree).  tools/physics_fit.py flies the oracle through the same two steps with the hidden controller state of
+    every wingman (z-velocity and linear-velocity integrators, which survive a respawn: quadcopter.py:433-478) fitted, and
+    scores the 147 recorded numbers in units of their motor-noise scatter.  NOT a parity test — neither package
+    can be run here — but the strongest constraint on the restated L0 there is:
+
+      * the DEFAULT table (PyFlyt's cf2x as recalled) reproduces every sign, near-hover thrust and zero
+        yaw, but its attitude loop is 2-3x too slow (recorded / simulated tilt 1.8-3.2 after one step).  Only UPPER bounds are
+        asserted on it: a correction of the table must not break this test;
+      * the RECORDED_FIT preset (te_quad_preset 1: ang_vel_kp x 6, motor_tau x 0.4) brings tilt, speed and rates to 1 within
+        the scatter (chi^2 / dof 0.3 on the default table's noise yardstick)."""
+    F = _fit_module()
+    base = F.make_cfg()
+    sigma = F.noise_sigma(base, 150)
+    # signs and orders of magnitude with the default table (hidden state fitted)
+    chi2, hid, sims = F.fit(base, sigma)
+    for w in range(F.W):
+        t, s = F.recorded(w), sims[w]
+        for k in (0, 1, 3, 4):   # vx, vy, roll, pitch after one step: the command's horizontal direction shows up with the right sign
+            if abs(t[k]) > 3 * sigma[k]:
+                assert np.sign(s[k]) == np.sign(t[k]), (w, k)
+        assert abs(t[5]) < 0.01 and abs(s[5]) < 0.01            # no yaw command, no yaw
+        assert abs(s[2]) < 0.3 and abs(t[2]) < 0.3              # near-hover thrust from the first sub-steps
+        assert 0.4 < hid[w, 0] < 0.75                           # the fitted z integrator sits near (below) the hover throttle 0.67
+    r0 = F.ratios(sims)
+    for name, hi in {"tilt1": 4.0, "tilt2": 2.5, "rate1": 3.0, "speed1": 5.0}.items():
+        assert 0.7 < r0[name][0] and r0[name][1] < hi, (name, r0[name])
+    # the fitted preset
+    fit = F.row("preset 1", F.make_cfg(preset=1), sigma)
+    assert fit["chi2_dof"] < 1.0 and fit["chi2_dof"] < 0.2 * chi2 / F.DOF, (fit["chi2_dof"], chi2 / F.DOF)
+    for name, (lo, hi) in {"tilt1": (0.9, 1.3), "tilt2": (0.9, 1.25), "rate1": (0.7, 1.5), "speed1": (0.7, 1.2)}.items():
+        assert lo < fit["ratios"][name][0] and fit["ratios"][name][1] < hi, (name, fit["ratios"][name])
+
+
+def test_fitted_preset_still_flies():
+    """te_quad_preset(TE_QUAD_CF2X_RECORDED_FIT): hover equilibrium, velocity tracking and the mode-7 hold with the stiffer rate
+    loop and the near-instant motors (dt / tau = 1.04: the discrete lag must not ring)."""
+    cfg = O.default_config("exp03", quad_preset=1)
+    assert cfg.quad_preset == 1 and abs(cfg.quad.motor_tau - 0.004) < 1e-9 and abs(cfg.quad.ang_vel_kp[0] - 0.048) < 1e-9
+    assert abs(cfg.quad.ang_vel_kp[2] - 0.01) < 1e-9            # yaw untouched
+    pos, vel, eul, thr = O.fly(cfg, 6, [0, 0, 0, 0], 240 * 8, [0, 0, 5])
+    hover = np.sqrt(cfg.quad.mass * cfg.quad.gravity / cfg.quad.total_thrust)
+    np.testing.assert_allclose(thr[-1], hover, atol=2e-3)
+    assert abs(vel[-1, 2]) < 5e-3 and np.abs(eul).max() < 1e-6
+    pos, vel, eul, thr = O.fly(cfg, 6, [0.6, 0, 0, 0.2], 240 * 6, [0, 0, 5])
+    assert abs(vel[-1, 0] - 0.6) < 0.02 and abs(vel[-1, 2] - 0.2) < 0.02 and np.abs(eul).max() < 0.5
+    cfg7 = O.default_config("stage01", quad_preset=1)
+    pos, vel, eul, thr = O.fly(cfg7, 7, [1.0, 0.0, 0, 1.0], 240 * 15, [0, 0, 1.0])
+    assert np.abs(pos[-1] - [1.0, 0.0, 1.0]).max() < 0.05
+
+
+def test_control_every_substep_switch():
+    """cfg.control_every_substep = 0: QuadX.update_control on every second physics sub-step (PyFlyt's own 120 Hz), the motors
+    keep the last pwm in between.  Same equilibrium, different transient."""
+    a = O.default_config("exp03")
+    b = O.default_config("exp03", control_every_substep=0)
+    pa, va, ea, ta = O.fly(a, 6, [0.5, 0.2, 0, 0.1], 240 * 6, [0, 0, 5])
+    pb, vb, eb, tb = O.fly(b, 6, [0.5, 0.2, 0, 0.1], 240 * 6, [0, 0, 5])
+    assert np.abs(va[-1] - [0.5, 0.2, 0.1]).max() < 0.03 and np.abs(vb[-1] - [0.5, 0.2, 0.1]).max() < 0.05
+    assert np.abs(va[:240] - vb[:240]).max() > 1e-3     # the transient differs: the integrators run at half the rate
+    # at 120 Hz the pwm of an odd sub-step is the previous one's: throttle changes twice as rarely
+    assert np.abs(tb[:40] - ta[:40]).max() > 1e-4

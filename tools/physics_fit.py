@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Sensitivity study of the restated quadrotor physics against the only PyBullet + PyFlyt output in the reference tree.
+
+    python tools/physics_fit.py [--pairs] [--json out.json]          (CPU only, a minute or two)
+
+Evidence: tests/golden/ref_level5_obs.npz = the decoded src/core/rl_framework/utils/output/collect_and_save/io_data0.h5:
+the IMU reads (body velocity, euler angles, body rates, position) of seven wingmen at two consecutive env-steps right after a
+(re)spawn, each obeying the behaviour tree's 0.6 m/s command (level5_dumb_multiobs.py:116-150).  7 x 2 x 9 numbers + 7 position
+differences = 147 observables.
+
+Model: oracle/te_oracle.c (the CPU restatement of PyFlyt 0.11.1 QuadX + Bullet's free-body step; the HIP kernels reproduce it to
+3e-5) flown for 32 sub-steps from rest with the recorded commands (ote_fly_hidden), motor noise off.
+
+What the recording does NOT hold is the controller state at release: PID memories survive disarm / replace / arm
+(quadcopter.py:433-478: only body / motors / set-point / pwm are reset), so each wingman starts with an unknown z-velocity
+integrator and unknown linear-velocity integrators (bounded by their limits).  These 3 numbers per wingman are FITTED for
+every candidate parameter set, so that a candidate is never blamed for (or saved by) the hidden state.
+
+Noise: the motor noise (2 % multiplicative, per motor, per sub-step) makes the recording one draw of a distribution.  Its
+standard deviation per observable comes from a Monte-Carlo run of the oracle with the noise on; residuals are in those units
+and chi^2 / dof ~ 1 means "indistinguishable from the recording".
+
+Scan: every entry of the cf2x table (te_config.c: cf2x_defaults) that acts on this manoeuvre is multiplied by a factor on a log
+grid, one at a time, then in pairs (--pairs); plus the two structural switches (update_control every sub-step or at 120 Hz; PID
+period 1/120 or 1/240).  Reported per candidate: chi^2 / dof, and the four ratios recorded / simulated that
+tests/test_oracle_physics.py tracks (tilt after one and two steps, body rate and horizontal speed after one step).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+from scipy.optimize import least_squares
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import te_oracle as O  # noqa: E402
+
+MAX_SPEED = 10 / 3.6
+
+
+def load():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_level5_obs.npz"))
+    I, A = g["inertial"].astype(np.float64), g["last_action"].astype(np.float64)
+    rec = dict(pos=I[:, 0:3] * 20.0, vel=I[:, 3:6] * MAX_SPEED, eul=I[:, 6:9] * np.pi, rate=I[:, 9:12] * 2 * np.pi)
+    sp = np.zeros((14, 4))
+    for k in range(14):
+        d = A[k, :3] / np.linalg.norm(A[k, :3])
+        sp[k] = [A[k, 3] * d[0], A[k, 3] * d[1], 0.0, A[k, 3] * d[2]]
+    return rec, sp
+
+
+REC, SP = load()
+W = 7
+SUB = (15, 31)  # the IMU read an observation carries: top of the 16th sub-step of its env-step (one-sub-step lag)
+
+
+def observables(out):
+    """21 numbers of one wingman from the oracle's per-sub-step IMU reads."""
+    pos, vel, eul, rate = out
+    return np.concatenate([vel[SUB[0]], eul[SUB[0]], rate[SUB[0]], vel[SUB[1]], eul[SUB[1]], rate[SUB[1]], pos[SUB[1]] - pos[SUB[0]]])
+
+
+def recorded(w):
+    return np.concatenate([REC["vel"][w], REC["eul"][w], REC["rate"][w], REC["vel"][w + W], REC["eul"][w + W], REC["rate"][w + W],
+                           REC["pos"][w + W] - REC["pos"][w]])
+
+
+def simulate(cfg, w, hidden3, noise_env=-1):
+    h = np.zeros(16)
+    h[0], h[2], h[3] = hidden3
+    return O.fly_hidden(cfg, 6, [SP[w], SP[w + W]], [0, 16], 32, [0, 0, 0], h, noise_env)
+
+
+def make_cfg(mult=None, control_every_substep=1, control_dt=None, preset=0):
+    cfg = O.default_config("level5", n_envs=1, quad_preset=preset)
+    q = cfg.quad
+    for name, m in (mult or {}).items():
+        if name == "inertia_xy": q.inertia[0] *= m; q.inertia[1] *= m
+        elif name == "ang_vel_kp_xy": q.ang_vel_kp[0] *= m; q.ang_vel_kp[1] *= m
+        elif name == "ang_vel_kd_xy": q.ang_vel_kd[0] *= m; q.ang_vel_kd[1] *= m
+        elif name == "ang_vel_ki_xy": q.ang_vel_ki[0] *= m; q.ang_vel_ki[1] *= m
+        elif name == "ang_pos_kp_xy": q.ang_pos_kp[0] *= m; q.ang_pos_kp[1] *= m
+        elif name in ("lin_vel_kp", "lin_vel_ki", "lin_vel_kd", "lin_vel_lim"):
+            arr = getattr(q, name); arr[0] *= m; arr[1] *= m
+        else:
+            setattr(q, name, getattr(q, name) * m)
+    cfg.control_every_substep = control_every_substep
+    if control_dt is not None:
+        cfg.control_dt = control_dt
+    return cfg
+
+
+def noise_sigma(cfg, n=300):
+    """Per-observable standard deviation under the motor noise, at hover-ish hidden state, averaged over the wingmen."""
+    hover = float(np.sqrt(cfg.quad.mass * cfg.quad.gravity / cfg.quad.total_thrust))
+    sig = np.zeros((W, 21))
+    for w in range(W):
+        obs = np.array([observables(simulate(cfg, w, (0.9 * hover, 0, 0), noise_env=1000 * w + k)) for k in range(n)])
+        sig[w] = obs.std(0)
+    s = sig.mean(0)
+    return np.maximum(s, 1e-4)  # deterministic channels (e.g. yaw) keep a floor
+
+
+def fit(cfg, sigma):
+    """Fit the hidden state of every wingman; return chi^2, per-wingman hidden states and simulated observables."""
+    hover = float(np.sqrt(cfg.quad.mass * cfg.quad.gravity / max(cfg.quad.total_thrust, 1e-9)))
+    lim = float(cfg.quad.lin_vel_lim[0])
+    chi2, hid, sims = 0.0, [], []
+    for w in range(W):
+        target = recorded(w)
+
+        def res(h):
+            r = (observables(simulate(cfg, w, h)) - target) / sigma
+            return np.where(np.isfinite(r), r, 1e3)   # an unstable candidate (e.g. dt / motor_tau > 1) is simply a bad one
+        best = None
+        for z0 in (min(0.9 * hover, 0.99), min(0.6 * hover, 0.9)):
+            r = least_squares(res, x0=[z0, 0.0, 0.0], bounds=([0.0, -lim, -lim], [1.0, lim, lim]), diff_step=1e-4, xtol=1e-10, ftol=1e-10)
+            if best is None or r.cost < best.cost:
+                best = r
+        chi2 += 2 * best.cost
+        hid.append(best.x)
+        sims.append(observables(simulate(cfg, w, best.x)))
+    return chi2, np.array(hid), np.array(sims)
+
+
+def ratios(sims):
+    """recorded / simulated: tilt after one and two steps, body rate and horizontal speed after one step (7 wingmen each)."""
+    out = {k: [] for k in ("tilt1", "tilt2", "rate1", "speed1")}
+    for w in range(W):
+        t, s = recorded(w), sims[w]
+        out["tilt1"].append(np.hypot(*t[3:5]) / np.hypot(*s[3:5]))
+        out["tilt2"].append(np.hypot(*t[12:14]) / np.hypot(*s[12:14]))
+        out["rate1"].append(np.hypot(*t[6:8]) / np.hypot(*s[6:8]))
+        out["speed1"].append(np.hypot(*t[0:2]) / np.hypot(*s[0:2]))
+    return {k: (float(np.min(v)), float(np.max(v))) for k, v in out.items()}
+
+
+DOF = W * 21 - W * 3
+
+
+def row(label, cfg, sigma, own=False):
+    """chi^2 / dof in units of the DEFAULT table's motor-noise scatter (one yardstick for the whole scan).  own=True adds the
+    candidate's own scatter (a stiffer attitude loop rejects motor noise: its sigma is up to 5x smaller, so the same residual
+    weighs more) and -2 log L = chi^2_own + 2 sum log sigma_own (+ const), the number candidates are finally ranked by."""
+    chi2, hid, sims = fit(cfg, sigma)
+    r = ratios(sims)
+    out = dict(label=label, chi2_dof=chi2 / DOF, ratios=r, all_within_20pct=all(0.8 <= lo and hi <= 1.2 for lo, hi in r.values()),
+               zv_i=[float(x) for x in hid[:, 0]], lv_i_absmax=float(np.abs(hid[:, 1:]).max()))
+    if own:
+        sig = noise_sigma(cfg, 200)
+        c2, _, sims2 = fit(cfg, sig)
+        out.update(chi2_own_dof=c2 / DOF, m2logL=float(c2 + 2 * W * np.log(sig).sum()), ratios_own=ratios(sims2))
+    return out
+
+
+def fmt(r):
+    q = r["ratios"]
+    own = f" {r['chi2_own_dof']:.2f} | {r['m2logL']:.0f} |" if "m2logL" in r else " | |"
+    return (f"| {r['label']} | {r['chi2_dof']:.2f} | " + " | ".join(f"{q[k][0]:.2f}-{q[k][1]:.2f}" for k in ("tilt1", "tilt2", "rate1", "speed1"))
+            + f" | {'yes' if r['all_within_20pct'] else 'no'} |" + own)
+
+
+SINGLE = ["ang_vel_kp_xy", "ang_vel_kd_xy", "ang_pos_kp_xy", "lin_vel_kp", "lin_vel_ki", "lin_vel_kd", "lin_vel_lim", "inertia_xy", "arm",
+          "total_thrust", "motor_tau", "z_vel_kp", "z_vel_ki", "z_vel_kd", "drag_coef_xyz", "drag_coef_pqr", "mass"]
+GRID = [0.1, 0.2, 0.33, 0.5, 0.67, 0.8, 1.25, 1.5, 2.0, 3.0, 4.0, 6.0, 8.0, 12.0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", action="store_true", help="also scan pairs of the best single parameters")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--headline", action="store_true", help="only the named candidates (default table, the two structural switches, the preset, the shortlist)")
+    args = ap.parse_args()
+    base = make_cfg()
+    sigma = noise_sigma(base)
+    names = ["vx1", "vy1", "vz1", "roll1", "pitch1", "yaw1", "p1", "q1", "r1", "vx2", "vy2", "vz2", "roll2", "pitch2", "yaw2", "p2", "q2", "r2", "dx", "dy", "dz"]
+    print("motor-noise sigma per observable:", {n: float(f"{s:.4g}") for n, s in zip(names, sigma)})
+    rows = []
+    print("| candidate | chi2/dof | tilt1 | tilt2 | rate1 | speed1 | all within 1 +- 0.2 | chi2/dof (own noise) | -2 log L |\n|---|---|---|---|---|---|---|---|---|")
+    for label, cfg in (("recalled table, control every sub-step (the default)", base),
+                       ("update_control at 120 Hz (control_every_substep = 0)", make_cfg(control_every_substep=0)),
+                       ("PID period 1/240 (control_dt = physics_dt)", make_cfg(control_dt=1 / 240)),
+                       ("recorded-fit preset (te_quad_preset 1: ang_vel_kp_xy x 6, motor_tau x 0.4)", make_cfg(preset=1)),
+                       ("120 Hz control + ang_vel_kp_xy x 4", make_cfg({"ang_vel_kp_xy": 4}, control_every_substep=0)),
+                       ("120 Hz control + ang_vel_kp_xy x 3, ang_pos_kp_xy x 1.25", make_cfg({"ang_vel_kp_xy": 3, "ang_pos_kp_xy": 1.25}, control_every_substep=0)),
+                       ("120 Hz control + ang_pos_kp_xy x 2, total_thrust x 2", make_cfg({"ang_pos_kp_xy": 2, "total_thrust": 2}, control_every_substep=0)),
+                       ("motor_tau x 0.5, arm x 6", make_cfg({"motor_tau": 0.5, "arm": 6})),
+                       ("motor_tau x 0.5, inertia_xy x 0.25", make_cfg({"motor_tau": 0.5, "inertia_xy": 0.25})),
+                       ("z_vel_kd x 8, ang_vel_kp_xy x 6", make_cfg({"z_vel_kd": 8, "ang_vel_kp_xy": 6}))):
+        rows.append(row(label, cfg, sigma, own=True)); print(fmt(rows[-1]), flush=True)
+    if args.headline:
+        if args.json:
+            json.dump(dict(sigma=dict(zip(names, map(float, sigma))), rows=rows), open(args.json, "w"), indent=1)
+        return
+    for ces, tag in ((1, ""), (0, "120 Hz control + ")):
+        best_single = {}
+        for name in SINGLE:
+            best = None
+            for m in GRID:
+                r = row(f"{tag}{name} x {m:g}", make_cfg({name: m}, control_every_substep=ces), sigma)
+                if best is None or r["chi2_dof"] < best["chi2_dof"]:
+                    best = r
+            best_single[name] = best
+            rows.append(best); print(fmt(best), flush=True)
+        if args.pairs:
+            top = sorted(best_single, key=lambda n: best_single[n]["chi2_dof"])[:5]
+            print("pairs over", top)
+            fine = [0.25, 0.33, 0.5, 0.67, 0.8, 1.0, 1.25, 1.5, 2.0, 3.0, 4.0, 6.0, 8.0]
+            for i, a in enumerate(top):
+                for b in top[i + 1:]:
+                    best = None
+                    for ma in fine:
+                        for mb in fine:
+                            r = row(f"{tag}{a} x {ma:g}, {b} x {mb:g}", make_cfg({a: ma, b: mb}, control_every_substep=ces), sigma)
+                            if best is None or r["chi2_dof"] < best["chi2_dof"]:
+                                best = r
+                    rows.append(best); print(fmt(best), flush=True)
+    if args.json:
+        json.dump(dict(sigma=dict(zip(names, map(float, sigma))), rows=rows), open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
