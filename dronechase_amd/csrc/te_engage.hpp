@@ -1,0 +1,442 @@
+// te_engage.hpp — the level4-family engage/observe kernel with the environment in REGISTERS.
+//
+// engage_observe_kernel (te_env.hip) runs a 256-thread block per 64 envs through barrier-separated phases over an LDS
+// copy of the block's state; its span is the critical path of one block (stage 6.5 + precompute 3.5 + logic 7.4 + spawn/rows
+// 5-12 + patch 0.5-5 us) and 60 % of its wave-cycles wait at s_waitcnt (profiles/r01_f_pmc_waits.txt).  At 65 536 envs there
+// are only 1 024 chunks for 1 024 SIMDs, so nothing is gained by the block's extra waves except the phases' parallelism, and
+// that is bought with six barriers and an LDS round trip for every operand.
+//
+// engage_kernel<PM, IM> instead gives every env ONE lane for the whole step and every chunk of 64 envs ONE wave (a
+// single-wave workgroup: no barrier ever waits for another wave):
+//   * every word the logic reads (IMU positions, armed flags, the pursuers' guns, the agent's IMU, the env record, the
+//     action) is requested up front with independent coalesced loads (planes are env-fastest: one load = one 256-byte
+//     line per wave) and lands in registers: ONE memory latency, then straight-line arithmetic.  The slot loops run over the
+//     compile-time capacity (PM pursuers, PM + IM slots) with the run-time counts as predicates, so the per-slot arrays
+//     stay in VGPRs (a run-time trip count would send them to scratch);
+//   * engagement, reward, termination, info, closer-wins LIDAR resolution, wave advance / auto-reset decision: the
+//     reference's order (exp03_vFinal_task.py:285-413,423-578), on bit masks;
+//   * the rare heavy parts are done by the WHOLE wave for the env that needs them: a new round or an auto-reset respawns up
+//     to D drones (Philox + trigonometry + ~40 stores each): lane k takes slot k; a terminal LIDAR tile (1 014 floats of
+//     ones) is streamed by all 64 lanes;
+//   * the allies' commands and the flight plan of the next sub-step launch come from the same registers.
+// Kernel span = one wave's straight-line path (~2 000 VALU instructions + one load round trip) instead of a block's phase chain.
+//
+// Covers the level4 task family (exp02/03/04/05, evaluation, level5's engage step) for P <= PM and P + I <= PM + IM; other
+// shapes and the stage01 / stage02 families keep engage_observe_kernel.  TE_ENGAGE=lds selects the LDS kernel for A/B runs.
+//
+// Reference citations are file:line under the reference's src/ tree.
+#pragma once
+#include "te_logic.hpp"
+#include "te_stacked.hpp"
+
+namespace te {
+
+template <class V> TE_DEV void plan_slot_l4(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint32_t& dense, int& n) {
+  const unsigned long long b = __ballot(a);
+  const int cnt = __popcll(b);
+  if (cnt == 0) return;
+  if (s == 0 || cnt >= dense_min || n + cnt > kMixedCap) { dense |= 1u << s; return; }
+  if (a) items[n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | (s << 8));
+  n += cnt;
+}
+
+// Task.setup_round / Task.on_reset for ONE slot (level4_spawn_slot), also telling the caller where the drone ended up
+TE_DEV bool spawn_slot_at(const te_config& c, const GView& v, int s, int round, uint32_t episode, bool reset, V3& where) {
+  const int Pn = c.n_pursuers;
+  bool armed_now = false;
+  if (s >= Pn) {
+    disarm(v, s);
+    const int i = s - Pn;
+    if (i < round && i < c.n_invaders) {
+      U4 r = env_rng(c, v.env, RNG_SPAWN_INVADER, (uint32_t)s, 0, episode, (uint32_t)round);
+      where = level4_position(c, c.born_radius, u01(r.x), u01(r.y));
+      respawn_armed(c, v, s, where);
+      armed_now = true;
+    }
+  } else if (reset) {
+    U4 r = env_rng(c, v.env, RNG_SPAWN_PURSUER, (uint32_t)s, 0, episode, 0);
+    where = level4_position(c, c.pursuer_spawn_radius, u01(r.x), u01(r.y));
+    respawn_armed(c, v, s, where);
+    armed_now = true;
+    if (driven_externally(c, s)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v.sf(TE_D_ALLY_ACTION + k, s, 0.0f);
+    }
+  }
+  if (s >= Pn || reset) v.si(TE_D_NAV_STATE, s, TE_NAV_WAIT);
+  return armed_now;
+}
+
+template <int PM, int IM>
+__global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+  constexpr int DM = PM + IM;
+  __shared__ float xs[DM][4];  // positions of the slots a wave has just respawned, handed back to the env's own lane
+  const te_config& c = p.cfg;
+  const int D = p.D, P = c.n_pursuers;
+  const int lane = threadIdx.x;
+  const int env = blockIdx.x * 64 + lane;
+  const bool valid = env < p.N;   // planes are padded to Npad (a multiple of 64): lanes beyond N load in bounds and store nothing
+  const GView g{p.dstate, p.estate, D, p.Npad, env, P};
+  const uint32_t pur_bits = (1u << P) - 1u, all_bits = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u), inv_bits = all_bits & ~pur_bits;
+
+  // ---- one round of independent loads ----------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dstate, 0, (int)((uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)D * (uint32_t)p.Npad * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(p.estate, 0, (int)((uint32_t)TE_ENV_WORDS * (uint32_t)p.Npad * 4u), 0x00020000);
+  const int voff = env * 4;
+  const uint32_t plane = (uint32_t)p.Npad * 4u;   // bytes between two slots of a word; D * plane between two words
+  auto ld = [&](int w, int s) { return __builtin_amdgcn_raw_buffer_load_b32(rd, voff, (int)(((uint32_t)w * (uint32_t)D + (uint32_t)s) * plane), 0); };
+  auto le = [&](int w) { return __builtin_amdgcn_raw_buffer_load_b32(re, voff, (int)((uint32_t)w * plane), 0); };
+  float px[DM], py[DM], pz[DM];
+  uint32_t armed_w[DM];
+  int mun[PM], lf[PM];
+  float fx[PM], fy[PM], fz[PM];   // FORMATION of the pursuers (the behaviour tree's MoveToFormation target)
+#pragma unroll
+  for (int s = 0; s < DM; ++s) {
+    px[s] = py[s] = pz[s] = 0.0f; armed_w[s] = 0u;
+    if (s < D) {
+      px[s] = __uint_as_float(ld(TE_D_OBS_POS, s)); py[s] = __uint_as_float(ld(TE_D_OBS_POS + 1, s)); pz[s] = __uint_as_float(ld(TE_D_OBS_POS + 2, s));
+      armed_w[s] = ld(TE_D_ARMED, s);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PM; ++q) {
+    mun[q] = 0; lf[q] = 0; fx[q] = fy[q] = fz[q] = 0.0f;
+    if (q < P) {
+      mun[q] = (int)ld(TE_D_MUNITION, q); lf[q] = (int)ld(TE_D_LAST_FIRED, q);
+      fx[q] = __uint_as_float(ld(TE_D_FORMATION, q)); fy[q] = __uint_as_float(ld(TE_D_FORMATION + 1, q)); fz[q] = __uint_as_float(ld(TE_D_FORMATION + 2, q));
+    }
+  }
+  float ag[9];  // OBS_EULER, OBS_VEL, OBS_RATE of the agent
+#pragma unroll
+  for (int k = 0; k < 9; ++k) ag[k] = __uint_as_float(ld(TE_D_OBS_EULER + k, 0));
+  int step = (int)le(TE_E_STEP) + 1;  // AGENT_STEP_BROADCAST (exp03_vFinal_environment.py:177-182)
+  int max_step = (int)le(TE_E_MAX_STEP);
+  int round = (int)le(TE_E_ROUND);
+  const float last_dist = __uint_as_float(le(TE_E_LAST_DIST));
+  int agent_kills = (int)le(TE_E_AGENT_KILLS), allies_kills = (int)le(TE_E_ALLIES_KILLS), deads = (int)le(TE_E_DEADS);
+  uint32_t episode = le(TE_E_EPISODE);
+  float4 act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (valid) act = reinterpret_cast<const float4*>(actions)[env];
+
+  // ---- masks, closest invader of every pursuer (OffsetHandler over the drones armed NOW, offsets_handler.py:68-95) -------
+  uint32_t S = 0u, zone = 0u, org = 0u;
+#pragma unroll
+  for (int s = 0; s < DM; ++s) {
+    if (s < D && armed_w[s] != 0u) {
+      S |= 1u << s;
+      const float n = norm(V3{px[s], py[s], pz[s]});
+      zone |= (n > c.dome_radius ? 1u : 0u) << s;
+      org |= (n < c.origin_range ? 1u : 0u) << s;
+    }
+  }
+  if (!valid) S = 0u;
+  int tgt[PM]; float dmin[PM];
+#pragma unroll
+  for (int q = 0; q < PM; ++q) {
+    tgt[q] = -1; dmin[q] = 0.0f;
+    if (q < P && ((S >> q) & 1u)) {
+#pragma unroll
+      for (int j = 1; j < DM; ++j) {   // identify_closest_invader (offsets_handler.py:256-281): strict '<' in slot order
+        if (j >= P && ((S >> j) & 1u)) {
+          const float d = dist(V3{px[q], py[q], pz[q]}, V3{px[j], py[j], pz[j]});
+          if (tgt[q] < 0 || d < dmin[q]) { tgt[q] = j; dmin[q] = d; }
+        }
+      }
+    }
+  }
+  auto pos_of = [&](int s) {  // position of a run-time slot: a select chain, never an indexed register file
+    V3 r{0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < DM; ++k) if (k == s) r = V3{px[k], py[k], pz[k]};
+    return r;
+  };
+
+  uint32_t A = S;
+  if (valid) {
+    g.esf(TE_E_LAST_ACTION + 0, act.x); g.esf(TE_E_LAST_ACTION + 1, act.y); g.esf(TE_E_LAST_ACTION + 2, act.z); g.esf(TE_E_LAST_ACTION + 3, act.w);
+    g.esi(TE_E_STEP, step);
+    g.esi(TE_E_SNAP_MASK, (int)S);
+  }
+  auto kill = [&](int j) { disarm(g, j); A &= ~(1u << j); };
+  int agent_shots = 0, ally_shots = 0, exploded = 0, pursuer_suicided = 0, agent_suicided = 0;
+  // process_shoot_range_invaders (exp03_vFinal_task.py:392-413)
+#pragma unroll
+  for (int q = 0; q < PM; ++q) {
+    if (q < P && valid && ((S >> q) & 1u) && tgt[q] >= 0 && dmin[q] < c.shoot_range && gun_available(c, mun[q], lf[q], step) && mun[q] > 0) {
+      mun[q] -= 1; lf[q] = step;
+      g.si(TE_D_MUNITION, q, mun[q]); g.si(TE_D_LAST_FIRED, q, step);
+      const U4 r = env_rng(c, env, RNG_HIT, (uint32_t)q, 0, episode, (uint32_t)step);
+      if (u01(r.x) < c.hit_prob) {  // gun.py:94; entities_manager.shoot_by_ids (:238-248)
+        kill(tgt[q]);
+        if (q == 0) agent_shots += 1; else ally_shots += 1;
+        if (c.evaluation) g.si(TE_D_KILLS, q, g.gi(TE_D_KILLS, q) + 1);  // lw_kills (evaluation_task.py:498-499)
+      }
+    }
+  }
+  // process_explosion_range_invaders (:359-390) on the same (stale) distances
+#pragma unroll
+  for (int q = 0; q < PM; ++q) {
+    if (q < P && valid && ((S >> q) & 1u) && tgt[q] >= 0 && dmin[q] < c.explosion_range) {
+      kill(q); kill(tgt[q]);
+      if (mun[q] == 0 && q == 0) agent_suicided += 1;
+      else if (mun[q] == 0) pursuer_suicided += 1;
+      else exploded += 1;
+    }
+  }
+  agent_kills += agent_shots; allies_kills += ally_shots; deads += exploded;
+  // process_invaders_in_origin (:656-659); commented out in Evaluation_Task.on_step_middle (evaluation_task.py:397)
+  if (!c.evaluation && valid)
+    for (uint32_t m = org & inv_bits; m; m &= m - 1) kill(__ffs(m) - 1);
+
+  // compute_reward (:423-515); Evaluation_Task.compute_reward returns 0 (evaluation_task.py:508-515)
+  float reward = 0.0f, cur_dist = last_dist;
+  const V3 apos{px[0], py[0], pz[0]};
+  if (!c.evaluation) {
+    float gs[3];
+    gun_state(c, mun[0], lf[0], step, max_munition_of(c, 0), gs);
+    const float dist_origin = norm(apos);
+    int ally = -1;  // identify_closest_ally (offsets_handler.py:167-190)
+    if ((S & 1u) && __popc(S & pur_bits) > 1) {
+      float bd = 0.0f;
+#pragma unroll
+      for (int a = 1; a < PM; ++a) {
+        if (a < P && ((S >> a) & 1u)) {
+          const float d = dist(V3{px[a], py[a], pz[a]}, apos);
+          if (ally < 0 || d < bd) { ally = a; bd = d; }
+        }
+      }
+    }
+    int target = -1;
+#pragma unroll
+    for (int q = 0; q < PM; ++q) if (q == (ally < 0 ? 0 : ally) && ((S >> q) & 1u)) target = tgt[q];
+    const V3 tp = target >= 0 ? pos_of(target) : V3{0.0f, 0.0f, 0.0f};
+    cur_dist = dist(apos, tp);
+    const bool ready = gs[2] == 1.0f || gs[0] == 0.0f;
+    float bonus = 0.0f, penalty = 0.0f;
+    if (0.01f < last_dist - cur_dist && ready) bonus += c.approach_bonus_gain * norm(V3{ag[3], ag[4], ag[5]});
+    const float score = ready ? -cur_dist : cur_dist * (2.0f * gs[1] - 1.0f);
+    if (agent_shots > 0 || agent_suicided > 0) bonus += (float)(agent_shots + agent_suicided) * 1000.0f;
+    if (ally_shots > 0 || pursuer_suicided > 0) bonus += 0.5f * (float)(ally_shots + pursuer_suicided) * 1000.0f;
+    else if (exploded > 0) penalty += 1000.0f * (float)exploded;
+    if (apos.z < -5.0f) penalty += (-5.0f - apos.z) * 1000.0f;
+    if (zone & pur_bits) penalty += 1000.0f;
+    if (dist_origin > c.born_radius - 2.0f) penalty += dist_origin - c.born_radius - 2.0f;  // literal
+    reward = score + bonus - penalty;
+  }
+  // increment_max_step (:150-153), compute_termination (:517-569)
+  if (agent_shots + ally_shots > 0) max_step += c.step_increment;
+  const int armed_invaders = __popc(A & inv_bits), armed_pursuers = __popc(A & pur_bits);
+  const bool all_rounds_over = armed_invaders == 0 && round >= c.n_rounds;
+  bool term;
+  if (c.evaluation) term = (c.max_step > 0 && step > max_step) || all_rounds_over || zone != 0u || armed_pursuers == 0;
+  else term = step > max_step || all_rounds_over || zone != 0u || armed_pursuers == 0 || !(A & 1u) || apos.z < -5.99f;
+  const bool to_terminal = valid && term && c.auto_reset;
+  if (valid) {
+    if (!c.evaluation) g.esf(TE_E_LAST_DIST, cur_dist);
+    g.esi(TE_E_AGENT_KILLS, agent_kills); g.esi(TE_E_ALLIES_KILLS, allies_kills); g.esi(TE_E_DEADS, deads);
+    if (agent_shots + ally_shots > 0) g.esi(TE_E_MAX_STEP, max_step);
+    o.reward[env] = reward;
+    o.done[env] = term ? 1 : 0;
+    reinterpret_cast<int4*>(o.info)[env] = make_int4(agent_kills, allies_kills, deads, round);
+  }
+
+  // ---- the agent's own sphere: LidarMath.reframe + binning of every other drone armed NOW, closer wins in slot order
+  // (fused_lidar.py:143-217, lidar_math.py:53-83,262-311); empty right after a reset (step 0 never gets here)
+  uint32_t owners = 0u;
+  uint32_t cell[DM]; float rhat[DM];
+  {
+    const Q4 q = quat_of_euler(V3{ag[0], ag[1], ag[2]});
+    const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    const M3 R = rotation(Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2});
+#pragma unroll
+    for (int j = 1; j < DM; ++j) {
+      cell[j] = 0u; rhat[j] = 1.0f;
+      if (j < D && ((A >> j) & 1u)) {
+        int cj; lidar_cell(c, mul(R, sub(V3{px[j], py[j], pz[j]}, apos)), cj, rhat[j]);
+        cell[j] = (uint32_t)cj;
+        bool placed = false;
+#pragma unroll
+        for (int k = 1; k < j; ++k) {
+          if (!placed && ((owners >> k) & 1u) && cell[k] == cell[j]) {
+            if (rhat[j] < rhat[k]) owners = (owners & ~(1u << k)) | (1u << j);
+            placed = true;
+          }
+        }
+        if (!placed && rhat[j] < 1.0f) owners |= 1u << j;   // an empty cell holds 1.0
+      }
+    }
+  }
+  // ---- level5: what this step's stacked observation may look at, BEFORE anything respawns (te_stacked.hpp SnapRows)
+  if (p.snap && valid) {
+    const SnapRows sr{D, P};
+#pragma unroll
+    for (int s = 0; s < DM; ++s) {
+      if (s < D) {
+        p.snap[(size_t)(sr.pos() + 0 * D + s) * p.Npad + env] = __float_as_uint(px[s]);
+        p.snap[(size_t)(sr.pos() + 1 * D + s) * p.Npad + env] = __float_as_uint(py[s]);
+        p.snap[(size_t)(sr.pos() + 2 * D + s) * p.Npad + env] = __float_as_uint(pz[s]);
+      }
+    }
+    for (int k = 0; k < 3; ++k)
+      for (int s = 0; s < P; ++s) p.snap[(size_t)(sr.euler() + k * P + s) * p.Npad + env] = (uint32_t)g.gi(TE_D_OBS_EULER + k, s);
+    p.snap[(size_t)sr.armed() * p.Npad + env] = A;
+    p.snap[(size_t)sr.step() * p.Npad + env] = (uint32_t)step;
+    p.snap[(size_t)sr.episode() * p.Npad + env] = episode;
+    p.snap[(size_t)sr.done() * p.Npad + env] = to_terminal ? 1u : 0u;
+  }
+  // ---- terminal observation of an auto-reset env (SB3 VecEnv: infos[i]["terminal_observation"]): rows from this lane
+  auto inertial_row = [&](float* dst, float x, float y, float z, const float a9[9], int mu, int lfi, int st) {
+    const float two_pi = 2.0f * kPi;
+    dst[0] = clampf(x / c.dome_radius, -1.0f, 1.0f); dst[1] = clampf(y / c.dome_radius, -1.0f, 1.0f); dst[2] = clampf(z / c.dome_radius, -1.0f, 1.0f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      dst[3 + k] = clampf(a9[3 + k] / c.max_speed, -1.0f, 1.0f);
+      dst[6 + k] = clampf(a9[k] / kPi, -1.0f, 1.0f);
+      dst[9 + k] = clampf(a9[6 + k] / two_pi, -1.0f, 1.0f);
+    }
+    float gs[3];
+    gun_state(c, mu, lfi, st, max_munition_of(c, 0), gs);
+    dst[12] = gs[0]; dst[13] = gs[1]; dst[14] = gs[2];
+  };
+  if (to_terminal) {
+    if (o.term.inertial) inertial_row(o.term.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, px[0], py[0], pz[0], ag, mun[0], lf[0], step);
+    if (o.term.last_action) reinterpret_cast<float4*>(o.term.last_action)[env] = act;
+  }
+  // terminal LIDAR tiles: ones by the whole wave, env by env (rare), drained before any patch lands on them
+  if (o.term.lidar) {
+    unsigned long long tb = __ballot(to_terminal);
+    if (tb) {
+      for (; tb; tb &= tb - 1) {
+        const int l = __ffsll((long long)tb) - 1;
+        float* tile = o.term.lidar + (size_t)(blockIdx.x * 64 + l) * TE_OBS_LIDAR_WORDS;
+        for (int e = lane; e < TE_OBS_LIDAR_WORDS; e += 64) tile[e] = 1.0f;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  // patch the hit cells into the background the sub-step kernel's fill waves wrote (lidar_math.py:305: flag = type / 5;
+  // time plane = Delta 1 of a 10-deep ring, perception_snapshot.py:36-37)
+  {
+    float* dst = to_terminal ? o.term.lidar : o.obs.lidar;
+    if (valid && dst) {
+      dst += (size_t)env * TE_OBS_LIDAR_WORDS;
+#pragma unroll
+      for (int j = 1; j < DM; ++j) {
+        if ((owners >> j) & 1u) {
+          dst[cell[j]] = rhat[j];
+          dst[TE_LIDAR_CELLS + cell[j]] = (float)(j < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
+          dst[2 * TE_LIDAR_CELLS + cell[j]] = 0.1f;
+        }
+      }
+    }
+  }
+
+  // ---- on_step_end (:321-333): next wave when this one is cleared and a pursuer is alive; SB3 auto-reset -------------------
+  uint32_t task = 0u;   // round | reset << 8: the slots of this env have to be respawned
+  uint32_t snap_mask = S;
+  auto mask_after_spawn = [&](int rnd, bool reset) {
+    uint32_t m = reset ? pur_bits : (A & pur_bits);
+    const int n = rnd < c.n_invaders ? rnd : c.n_invaders;
+    return m | ((((1u << n) - 1u) << P) & all_bits);
+  };
+  if (valid && !term && armed_invaders == 0 && armed_pursuers > 0) {
+    round = round + (round < c.n_rounds ? 1 : c.n_rounds);  // advance_round (:155-175)
+    snap_mask = mask_after_spawn(round, false);
+    g.esi(TE_E_ROUND, round); g.esi(TE_E_SNAP_MASK, (int)snap_mask);
+    task = (uint32_t)round;
+  }
+  if (to_terminal) {  // Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146): the env record here, the slots below
+    episode += 1u; step = 0; max_step = c.max_step; round = 1;
+    snap_mask = mask_after_spawn(1, true);
+    g.esi(TE_E_EPISODE, (int)episode); g.esi(TE_E_STEP, 0); g.esi(TE_E_MAX_STEP, c.max_step); g.esi(TE_E_ROUND, 1);
+    g.esi(TE_E_AGENT_KILLS, 0); g.esi(TE_E_ALLIES_KILLS, 0); g.esi(TE_E_DEADS, 0);
+    g.esf(TE_E_LAST_DIST, c.dome_radius);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.esf(TE_E_LAST_ACTION + k, 0.0f);
+    g.esi(TE_E_SNAP_MASK, (int)snap_mask);
+    act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ag[k] = 0.0f;
+    task = 1u | (1u << 8);
+  }
+  // ---- spawn: the D slots of a respawning env are taken by the lanes of the wave (lane k = slot k), env by env -------------
+  uint32_t armed_post = A;
+  {
+    unsigned long long sb = __ballot(task != 0u);
+    for (; sb; sb &= sb - 1) {
+      const int l = __ffsll((long long)sb) - 1;
+      const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)task, l);
+      const uint32_t ep = (uint32_t)__builtin_amdgcn_readlane((int)episode, l);
+      const bool reset = (t >> 8) != 0u;
+      if (lane < D) {
+        const GView gv{p.dstate, p.estate, D, p.Npad, (int)(blockIdx.x * 64 + l), P};
+        V3 w{0.0f, 0.0f, 0.0f};
+        const bool placed = spawn_slot_at(c, gv, lane, (int)(t & 0xFFu), ep, reset, w);
+        xs[lane][0] = w.x; xs[lane][1] = w.y; xs[lane][2] = w.z; xs[lane][3] = placed ? 1.0f : 0.0f;
+      }
+      __syncthreads();  // single-wave workgroup: orders the LDS hand-over, waits for nobody
+      if (lane == l) {
+#pragma unroll
+        for (int s = 0; s < DM; ++s)
+          if (s < D && xs[s][3] != 0.0f) { px[s] = xs[s][0]; py[s] = xs[s][1]; pz[s] = xs[s][2]; }
+        armed_post = snap_mask;   // = the mask after the spawn: the pursuers as they are (all armed on reset) + the round's invaders
+        if (reset) {
+#pragma unroll
+          for (int q = 0; q < PM; ++q)
+            if (q < P) { mun[q] = max_munition_of(c, q); lf[q] = -c.cooldown_steps; fx[q] = px[q]; fy[q] = py[q]; fz[q] = pz[q]; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- the observation of the state the step leaves (post-reset values for an auto-reset env)
+  if (valid) {
+    if (o.obs.inertial) inertial_row(o.obs.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, px[0], py[0], pz[0], ag, mun[0], lf[0], step);
+    if (o.obs.last_action) reinterpret_cast<float4*>(o.obs.last_action)[env] = act;
+  }
+  // ---- the pursuers' positions the invaders steer at during the next sub-step launch (TE_X_REF), and the scripted allies'
+  // commands of the next step (Task.on_step_start -> LoyalWingmanBehaviorTree.update, loyalwingman_navigator.py:238-352)
+  if (valid) {
+    int first_skipped = -1;  // drive_loyalwingmen: get_armed_pursuers()[1:] — with the agent dead the first armed ally is skipped
+    if (!c.evaluation && !(armed_post & 1u)) first_skipped = (armed_post & pur_bits & ~1u) ? __ffs(armed_post & pur_bits & ~1u) - 1 : -1;
+#pragma unroll
+    for (int q = 0; q < PM; ++q) {
+      if (q < P) {
+        g.sf(TE_X_REF + 0, q, px[q]); g.sf(TE_X_REF + 1, q, py[q]); g.sf(TE_X_REF + 2, q, pz[q]);
+        if ((q > 0 || c.evaluation) && ((armed_post >> q) & 1u) && q != first_skipped) {
+          float out[3] = {0.0f, 0.0f, 0.0f};
+          const bool ext = driven_externally(c, q);
+          if (!ext && c.ally_policy == TE_ALLY_BT) {
+            const V3 me{px[q], py[q], pz[q]};
+            if (gun_available(c, mun[q], lf[q], step)) {
+              int t = -1; float bd = 0.0f; V3 tp{0.0f, 0.0f, 0.0f};
+              if ((snap_mask >> q) & 1u) {
+#pragma unroll
+                for (int j = 1; j < DM; ++j) {
+                  if (j >= P && ((snap_mask >> j) & 1u)) {
+                    const V3 pj{px[j], py[j], pz[j]};
+                    const float d = dist(me, pj);
+                    if (t < 0 || d < bd) { t = j; bd = d; tp = pj; }
+                  }
+                }
+              }
+              cmd_toward(me, tp, c.ally_speed, out);
+            } else cmd_toward(me, V3{fx[q], fy[q], fz[q]}, c.ally_speed, out);
+          } else if (ext || c.ally_policy != TE_ALLY_FROZEN) {  // nobody / the caller's policy: the set-point persists
+            out[0] = g.gf(TE_D_SETPOINT + 0, q); out[1] = g.gf(TE_D_SETPOINT + 1, q); out[2] = g.gf(TE_D_SETPOINT + 3, q);
+          }
+          g.sf(TE_X_CMD + 0, q, out[0]); g.sf(TE_X_CMD + 1, q, out[1]); g.sf(TE_X_CMD + 2, q, out[2]);
+        }
+      }
+    }
+  }
+  // ---- what the next sub-step launch has to fly for this chunk (post-spawn flags)
+  {
+    uint32_t dense = 0u; int n = 0;
+    uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
+    for (int s = 0; s < D; ++s) plan_slot_l4<void>(items, p.dense_min, lane, s, valid && ((armed_post >> s) & 1u), dense, n);
+    if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = (uint32_t)n; }
+  }
+}
+
+}  // namespace te

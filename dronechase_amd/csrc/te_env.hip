@@ -31,6 +31,7 @@
 
 #include "te_logic.hpp"
 #include "te_stacked.hpp"
+#include "te_engage.hpp"
 
 namespace te {
 
@@ -739,6 +740,8 @@ struct te_env {
   int family;
   size_t lds_bytes;
   size_t stack_lds_bytes = 0;  // stacked_kernel (level5)
+  int engage_regs = 0;         // level4 family: 1 = engage_kernel<2, 9>, 2 = engage_kernel<6, 12> (te_engage.hpp: the env in registers, one wave per
+                               // chunk); 0 = engage_observe_kernel (LDS phases): other shapes, stage01 / stage02, TE_ENGAGE=lds
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
   uint32_t* ally_scratch = nullptr;  // te_observe_wingman: owner planes between its two launches (te_create allocates them when a wingman is caller-driven)
   int n_fill_waves = 256;  // fill waves of the sub-step kernel: one per CU of an MI355X; four per CU for the six-sphere background of
@@ -835,6 +838,11 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   e->p.kd = derive(*cfg);
   e->p.N = cfg->n_envs; e->p.D = D; e->p.Npad = (cfg->n_envs + 63) / 64 * 64;
   e->lds_bytes = (size_t)lds_rows(D, cfg->n_pursuers) * kEPB * sizeof(uint32_t);
+  if (e->family == FAM_LEVEL4) {
+    if (cfg->n_pursuers <= 2 && D <= 11) e->engage_regs = 1;
+    else if (cfg->n_pursuers <= 6 && D <= 18) e->engage_regs = 2;
+    if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "lds")) e->engage_regs = 0; }
+  }
   e->p.dense_min = kDenseMin;
   if (const char* v = getenv("TE_DENSE_MIN")) { int n = atoi(v); if (n >= 1 && n <= 65) e->p.dense_min = n; }
   if (cfg->stacked_obs) e->n_fill_waves = 1024;
@@ -1067,7 +1075,9 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   // output comes from stacked_kernel
   StepOut o{reward, done, info, ObsOut{stack ? nullptr : obs_lidar, obs_inertial, obs_last_action},
             ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}};
-  launch_by_family(e->family, [&](auto fam) {
+  if (e->engage_regs == 1) hipLaunchKernelGGL((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  else if (e->engage_regs == 2) hipLaunchKernelGGL((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  else launch_by_family(e->family, [&](auto fam) {
     if (e->k2_threads == 512) hipLaunchKernelGGL((engage_observe_kernel<FAM_LEVEL4, 512>), dim3(b2), dim3(512), e->lds_bytes, st, p, actions, o);
     else hipLaunchKernelGGL((engage_observe_kernel<decltype(fam)::value>), dim3(b2), dim3(256), e->lds_bytes, st, p, actions, o);
   });
