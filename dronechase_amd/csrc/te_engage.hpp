@@ -31,6 +31,17 @@
 
 namespace te {
 
+#ifdef TE_DEBUG_STAMPS
+// phase stamps of every workgroup (diagnostic builds only; tools/engage_stamps.py): idx 0..15 of the block's record
+#define TE_ESTAMP(idx, wait)                                                                                   \
+  do {                                                                                                         \
+    if (wait) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+    if (p.dbg && threadIdx.x == 0) p.dbg[64 + blockIdx.x * 16 + (idx)] = __builtin_amdgcn_s_memrealtime();     \
+  } while (0)
+#else
+#define TE_ESTAMP(idx, wait) do {} while (0)
+#endif
+
 template <class V> TE_DEV void plan_slot_l4(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint32_t& dense, int& n) {
   const unsigned long long b = __ballot(a);
   const int cnt = __popcll(b);
@@ -40,43 +51,72 @@ template <class V> TE_DEV void plan_slot_l4(uint16_t* __restrict__ items, int de
   n += cnt;
 }
 
-// Task.setup_round / Task.on_reset for ONE slot (level4_spawn_slot), also telling the caller where the drone ended up
-TE_DEV bool spawn_slot_at(const te_config& c, const GView& v, int s, int round, uint32_t episode, bool reset, V3& where) {
+// |a| and |a - b| on the native square root (1 ulp) instead of the correctly rounded sqrtf (~10 instructions each, ~45 calls)
+TE_DEV float fnorm(V3 a) { return fsqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+TE_DEV float fdist(V3 a, V3 b) { return fnorm(sub(a, b)); }
+
+// lidar_cell (te_logic.hpp) on the native sqrt / rcp and the polynomial asin / atan2 of the sub-step loop (1e-7 abs): a tenth of
+// libm's acosf + atan2f instructions, which were a third of this kernel's straight-line path
+TE_DEV void lidar_cell_fast(const te_config& c, V3 local, int& cell, float& rhat) {
+  const float r2 = local.x * local.x + local.y * local.y + local.z * local.z;
+  float theta = 0.0f, phi = 0.0f, r = 0.0f;
+  if (r2 != 0.0f) {
+    const float inv = rsq(r2);
+    r = r2 * inv;
+    theta = 0.5f * kPi - fast_asin(clampf(local.z * inv, -1.0f, 1.0f));
+    phi = fast_atan2(local.y, local.x);
+  }
+  rhat = clampf(r * rcp(c.lidar_radius), 0.0f, 1.0f);
+  const int ti = min(max((int)(theta * (1.0f / kPi) * (float)TE_LIDAR_NTHETA), 0), TE_LIDAR_NTHETA - 1);
+  const int pi = min(max((int)((phi + kPi) * (0.5f / kPi) * (float)TE_LIDAR_NPHI), 0), TE_LIDAR_NPHI - 1);
+  cell = ti * TE_LIDAR_NPHI + pi;
+}
+
+// Task.setup_round / Task.on_reset for ONE slot (te_logic.hpp: level4_spawn_slot = disarm [+ disarm + replace + IMU + arm]), with
+// every word written ONCE and nothing written for a slot that is dead and stays dead: 40 stores for a respawned drone, 15 for one
+// that is only disarmed, 1 for the others (the generic sequence writes 61 / 15 / 15).  A wave that respawns an env carries these
+// stores on its critical path.  `was_armed`: the slot's ARMED flag before the call.  Returns whether the slot ends up armed, at `where`.
+TE_DEV bool spawn_slot_at(const te_config& c, const GView& v, int s, int round, uint32_t episode, bool reset, bool was_armed, V3& where) {
   const int Pn = c.n_pursuers;
-  bool armed_now = false;
-  if (s >= Pn) {
-    disarm(v, s);
-    const int i = s - Pn;
-    if (i < round && i < c.n_invaders) {
-      U4 r = env_rng(c, v.env, RNG_SPAWN_INVADER, (uint32_t)s, 0, episode, (uint32_t)round);
-      where = level4_position(c, c.born_radius, u01(r.x), u01(r.y));
-      respawn_armed(c, v, s, where);
-      armed_now = true;
+  const bool invader = s >= Pn;
+  const bool respawn = invader ? (s - Pn < round && s - Pn < c.n_invaders) : reset;
+  if (respawn) {
+    const U4 r = invader ? env_rng(c, v.env, RNG_SPAWN_INVADER, (uint32_t)s, 0, episode, (uint32_t)round)
+                         : env_rng(c, v.env, RNG_SPAWN_PURSUER, (uint32_t)s, 0, episode, 0);
+    where = level4_position(c, invader ? c.born_radius : c.pursuer_spawn_radius, u01(r.x), u01(r.y));
+    const float w3[3] = {where.x, where.y, where.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // replace (quadcopter.py:433-439) + the IMU read of arm() (:445-459) + disarm's zeroes (:461-478)
+      v.sf(TE_D_POS + k, s, w3[k]); v.sf(TE_D_FORMATION + k, s, w3[k]); v.sf(TE_D_OBS_POS + k, s, w3[k]);
+      v.sf(TE_D_VEL + k, s, 0.0f); v.sf(TE_D_OMEGA + k, s, 0.0f);
+      v.sf(TE_D_OBS_EULER + k, s, 0.0f); v.sf(TE_D_OBS_VEL + k, s, 0.0f); v.sf(TE_D_OBS_RATE + k, s, 0.0f);
+      v.sf(TE_D_QUAT + k, s, 0.0f);
     }
-  } else if (reset) {
-    U4 r = env_rng(c, v.env, RNG_SPAWN_PURSUER, (uint32_t)s, 0, episode, 0);
-    where = level4_position(c, c.pursuer_spawn_radius, u01(r.x), u01(r.y));
-    respawn_armed(c, v, s, where);
-    armed_now = true;
-    if (driven_externally(c, s)) {
+    v.sf(TE_D_QUAT + 3, s, 1.0f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v.sf(TE_D_THROTTLE + k, s, 0.0f); v.sf(TE_D_SETPOINT + k, s, 0.0f); }
+    v.si(TE_D_ARMED, s, 1); v.si(TE_D_MUNITION, s, max_munition_of(c, s)); v.si(TE_D_LAST_FIRED, s, -c.cooldown_steps);
+    if (!invader && driven_externally(c, s)) {   // Exp05_vFinal_Task.init_globals: last_action = zeros
 #pragma unroll
       for (int k = 0; k < 4; ++k) v.sf(TE_D_ALLY_ACTION + k, s, 0.0f);
     }
-  }
-  if (s >= Pn || reset) v.si(TE_D_NAV_STATE, s, TE_NAV_WAIT);
-  return armed_now;
+  } else if (invader && was_armed) disarm(v, s);   // disarm_all_invaders: the others are dead already, their words are zero
+  if (invader || reset) v.si(TE_D_NAV_STATE, s, TE_NAV_WAIT);
+  return respawn;
 }
 
 template <int PM, int IM>
 __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __restrict__ actions, StepOut o) {
   constexpr int DM = PM + IM;
   __shared__ float xs[DM][4];  // positions of the slots a wave has just respawned, handed back to the env's own lane
+  __shared__ float rows[64 * TE_OBS_INERTIAL_WORDS];  // the chunk's [64, 15] inertial rows, transposed here so that they leave as 15 contiguous 256-byte stores
   const te_config& c = p.cfg;
   const int D = p.D, P = c.n_pursuers;
   const int lane = threadIdx.x;
   const int env = blockIdx.x * 64 + lane;
   const bool valid = env < p.N;   // planes are padded to Npad (a multiple of 64): lanes beyond N load in bounds and store nothing
   const GView g{p.dstate, p.estate, D, p.Npad, env, P};
+  TE_ESTAMP(0, 0);
   const uint32_t pur_bits = (1u << P) - 1u, all_bits = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u), inv_bits = all_bits & ~pur_bits;
 
   // ---- one round of independent loads ----------------------------------------------------------------------------------
@@ -86,6 +126,13 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   const uint32_t plane = (uint32_t)p.Npad * 4u;   // bytes between two slots of a word; D * plane between two words
   auto ld = [&](int w, int s) { return __builtin_amdgcn_raw_buffer_load_b32(rd, voff, (int)(((uint32_t)w * (uint32_t)D + (uint32_t)s) * plane), 0); };
   auto le = [&](int w) { return __builtin_amdgcn_raw_buffer_load_b32(re, voff, (int)((uint32_t)w * plane), 0); };
+  // stores: the same addressing (a 64-bit pointer per store costs ~5 VALU instructions of address arithmetic; this is one scalar
+  // multiply).  st: word w of the wave-uniform slot s; stv: word w of a per-lane slot; ste: env word
+  auto st = [&](int w, int s, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, rd, voff, (int)(((uint32_t)w * (uint32_t)D + (uint32_t)s) * plane), 0); };
+  auto stf = [&](int w, int s, float v) { st(w, s, __float_as_uint(v)); };
+  auto stv = [&](int w, int slot_off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, rd, slot_off, (int)((uint32_t)w * (uint32_t)D * plane), 0); };
+  auto ste = [&](int w, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, re, voff, (int)((uint32_t)w * plane), 0); };
+  auto stef = [&](int w, float v) { ste(w, __float_as_uint(v)); };
   float px[DM], py[DM], pz[DM];
   uint32_t armed_w[DM];
   int mun[PM], lf[PM];
@@ -118,30 +165,29 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   float4 act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (valid) act = reinterpret_cast<const float4*>(actions)[env];
 
+  TE_ESTAMP(1, 1);
   // ---- masks, closest invader of every pursuer (OffsetHandler over the drones armed NOW, offsets_handler.py:68-95) -------
+  // (branch-free on purpose: every pair is evaluated and masked, a few hundred VALU instructions; predicated skips cost more in
+  // exec-mask bookkeeping than the arithmetic they save, and the lanes of a wave disagree about which slots are armed anyway)
   uint32_t S = 0u, zone = 0u, org = 0u;
 #pragma unroll
   for (int s = 0; s < DM; ++s) {
-    if (s < D && armed_w[s] != 0u) {
-      S |= 1u << s;
-      const float n = norm(V3{px[s], py[s], pz[s]});
-      zone |= (n > c.dome_radius ? 1u : 0u) << s;
-      org |= (n < c.origin_range ? 1u : 0u) << s;
-    }
+    const uint32_t a = (s < D && armed_w[s] != 0u && valid) ? 1u : 0u;
+    const float n = fnorm(V3{px[s], py[s], pz[s]});
+    S |= a << s;
+    zone |= (a & (n > c.dome_radius ? 1u : 0u)) << s;
+    org |= (a & (n < c.origin_range ? 1u : 0u)) << s;
   }
-  if (!valid) S = 0u;
   int tgt[PM]; float dmin[PM];
 #pragma unroll
   for (int q = 0; q < PM; ++q) {
     tgt[q] = -1; dmin[q] = 0.0f;
-    if (q < P && ((S >> q) & 1u)) {
 #pragma unroll
-      for (int j = 1; j < DM; ++j) {   // identify_closest_invader (offsets_handler.py:256-281): strict '<' in slot order
-        if (j >= P && ((S >> j) & 1u)) {
-          const float d = dist(V3{px[q], py[q], pz[q]}, V3{px[j], py[j], pz[j]});
-          if (tgt[q] < 0 || d < dmin[q]) { tgt[q] = j; dmin[q] = d; }
-        }
-      }
+    for (int j = 1; j < DM; ++j) {   // identify_closest_invader (offsets_handler.py:256-281): strict '<' in slot order
+      const float d = fdist(V3{px[q], py[q], pz[q]}, V3{px[j], py[j], pz[j]});
+      const bool take = q < P && j >= P && ((S >> q) & (S >> j) & 1u) != 0u && (tgt[q] < 0 || d < dmin[q]);
+      tgt[q] = take ? j : tgt[q];
+      dmin[q] = take ? d : dmin[q];
     }
   }
   auto pos_of = [&](int s) {  // position of a run-time slot: a select chain, never an indexed register file
@@ -151,20 +197,24 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     return r;
   };
 
+  TE_ESTAMP(2, 0);
   uint32_t A = S;
   if (valid) {
-    g.esf(TE_E_LAST_ACTION + 0, act.x); g.esf(TE_E_LAST_ACTION + 1, act.y); g.esf(TE_E_LAST_ACTION + 2, act.z); g.esf(TE_E_LAST_ACTION + 3, act.w);
-    g.esi(TE_E_STEP, step);
-    g.esi(TE_E_SNAP_MASK, (int)S);
+    stef(TE_E_LAST_ACTION + 0, act.x); stef(TE_E_LAST_ACTION + 1, act.y); stef(TE_E_LAST_ACTION + 2, act.z); stef(TE_E_LAST_ACTION + 3, act.w);
+    ste(TE_E_STEP, (uint32_t)step);
+    ste(TE_E_SNAP_MASK, S);
   }
-  auto kill = [&](int j) { disarm(g, j); A &= ~(1u << j); };
+  // a kill only clears the drone's bit here; Quadcopter.disarm's stores (quadcopter.py:461-478) are issued once per killed
+  // drone after the engagement (ONE copy of the 15 stores in the code instead of one per call site), before anything respawns
+  uint32_t killed = 0u;
+  auto kill = [&](int j) { killed |= 1u << j; A &= ~(1u << j); };
   int agent_shots = 0, ally_shots = 0, exploded = 0, pursuer_suicided = 0, agent_suicided = 0;
   // process_shoot_range_invaders (exp03_vFinal_task.py:392-413)
 #pragma unroll
   for (int q = 0; q < PM; ++q) {
     if (q < P && valid && ((S >> q) & 1u) && tgt[q] >= 0 && dmin[q] < c.shoot_range && gun_available(c, mun[q], lf[q], step) && mun[q] > 0) {
       mun[q] -= 1; lf[q] = step;
-      g.si(TE_D_MUNITION, q, mun[q]); g.si(TE_D_LAST_FIRED, q, step);
+      st(TE_D_MUNITION, q, (uint32_t)mun[q]); st(TE_D_LAST_FIRED, q, (uint32_t)step);
       const U4 r = env_rng(c, env, RNG_HIT, (uint32_t)q, 0, episode, (uint32_t)step);
       if (u01(r.x) < c.hit_prob) {  // gun.py:94; entities_manager.shoot_by_ids (:238-248)
         kill(tgt[q]);
@@ -185,44 +235,21 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   }
   agent_kills += agent_shots; allies_kills += ally_shots; deads += exploded;
   // process_invaders_in_origin (:656-659); commented out in Evaluation_Task.on_step_middle (evaluation_task.py:397)
-  if (!c.evaluation && valid)
-    for (uint32_t m = org & inv_bits; m; m &= m - 1) kill(__ffs(m) - 1);
-
-  // compute_reward (:423-515); Evaluation_Task.compute_reward returns 0 (evaluation_task.py:508-515)
-  float reward = 0.0f, cur_dist = last_dist;
-  const V3 apos{px[0], py[0], pz[0]};
-  if (!c.evaluation) {
-    float gs[3];
-    gun_state(c, mun[0], lf[0], step, max_munition_of(c, 0), gs);
-    const float dist_origin = norm(apos);
-    int ally = -1;  // identify_closest_ally (offsets_handler.py:167-190)
-    if ((S & 1u) && __popc(S & pur_bits) > 1) {
-      float bd = 0.0f;
+  if (!c.evaluation && valid) { killed |= org & inv_bits; A &= ~(org & inv_bits); }
+  for (uint32_t m = killed; m; m &= m - 1) {   // Quadcopter.disarm: static body, velocities / motors / set-point zeroed
+    const int so = ((__ffs(m) - 1) * p.Npad + env) * 4;
+    stv(TE_D_ARMED, so, 0u);
 #pragma unroll
-      for (int a = 1; a < PM; ++a) {
-        if (a < P && ((S >> a) & 1u)) {
-          const float d = dist(V3{px[a], py[a], pz[a]}, apos);
-          if (ally < 0 || d < bd) { ally = a; bd = d; }
-        }
-      }
-    }
-    int target = -1;
+    for (int k = 0; k < 3; ++k) { stv(TE_D_VEL + k, so, 0u); stv(TE_D_OMEGA + k, so, 0u); }
 #pragma unroll
-    for (int q = 0; q < PM; ++q) if (q == (ally < 0 ? 0 : ally) && ((S >> q) & 1u)) target = tgt[q];
-    const V3 tp = target >= 0 ? pos_of(target) : V3{0.0f, 0.0f, 0.0f};
-    cur_dist = dist(apos, tp);
-    const bool ready = gs[2] == 1.0f || gs[0] == 0.0f;
-    float bonus = 0.0f, penalty = 0.0f;
-    if (0.01f < last_dist - cur_dist && ready) bonus += c.approach_bonus_gain * norm(V3{ag[3], ag[4], ag[5]});
-    const float score = ready ? -cur_dist : cur_dist * (2.0f * gs[1] - 1.0f);
-    if (agent_shots > 0 || agent_suicided > 0) bonus += (float)(agent_shots + agent_suicided) * 1000.0f;
-    if (ally_shots > 0 || pursuer_suicided > 0) bonus += 0.5f * (float)(ally_shots + pursuer_suicided) * 1000.0f;
-    else if (exploded > 0) penalty += 1000.0f * (float)exploded;
-    if (apos.z < -5.0f) penalty += (-5.0f - apos.z) * 1000.0f;
-    if (zone & pur_bits) penalty += 1000.0f;
-    if (dist_origin > c.born_radius - 2.0f) penalty += dist_origin - c.born_radius - 2.0f;  // literal (SURVEY.md C8)
-    reward = score + bonus - penalty;
+    for (int k = 0; k < 4; ++k) { stv(TE_D_THROTTLE + k, so, 0u); stv(TE_D_SETPOINT + k, so, 0u); }
   }
+
+  const V3 apos{px[0], py[0], pz[0]};
+  TE_ESTAMP(3, 0);
+  // (the sphere's patches are the kernel's slowest stores — scattered 32-byte sectors, ~2.8 us per hit and env at 65 536 envs,
+  // tools/patch_bench.hip — so they are issued as early as the data allows: right after the termination decision, which picks their
+  // buffer; the reward is worked out while they drain)
   // increment_max_step (:150-153), compute_termination (:517-569)
   if (agent_shots + ally_shots > 0) max_step += c.step_increment;
   const int armed_invaders = __popc(A & inv_bits), armed_pursuers = __popc(A & pur_bits);
@@ -231,15 +258,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   if (c.evaluation) term = (c.max_step > 0 && step > max_step) || all_rounds_over || zone != 0u || armed_pursuers == 0;
   else term = step > max_step || all_rounds_over || zone != 0u || armed_pursuers == 0 || !(A & 1u) || apos.z < -5.99f;
   const bool to_terminal = valid && term && c.auto_reset;
-  if (valid) {
-    if (!c.evaluation) g.esf(TE_E_LAST_DIST, cur_dist);
-    g.esi(TE_E_AGENT_KILLS, agent_kills); g.esi(TE_E_ALLIES_KILLS, allies_kills); g.esi(TE_E_DEADS, deads);
-    if (agent_shots + ally_shots > 0) g.esi(TE_E_MAX_STEP, max_step);
-    o.reward[env] = reward;
-    o.done[env] = term ? 1 : 0;
-    reinterpret_cast<int4*>(o.info)[env] = make_int4(agent_kills, allies_kills, deads, round);
-  }
-
+  TE_ESTAMP(4, 0);
   // ---- the agent's own sphere: LidarMath.reframe + binning of every other drone armed NOW, closer wins in slot order
   // (fused_lidar.py:143-217, lidar_math.py:53-83,262-311); empty right after a reset (step 0 never gets here)
   uint32_t owners = 0u;
@@ -249,23 +268,23 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
     const M3 R = rotation(Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2});
 #pragma unroll
-    for (int j = 1; j < DM; ++j) {
-      cell[j] = 0u; rhat[j] = 1.0f;
-      if (j < D && ((A >> j) & 1u)) {
-        int cj; lidar_cell(c, mul(R, sub(V3{px[j], py[j], pz[j]}, apos)), cj, rhat[j]);
-        cell[j] = (uint32_t)cj;
-        bool placed = false;
+    for (int j = 1; j < DM; ++j) {   // every slot is binned, armed or not (branch-free, as above); only armed ones may own a cell
+      int cj; lidar_cell_fast(c, mul(R, sub(V3{px[j], py[j], pz[j]}, apos)), cj, rhat[j]);
+      cell[j] = (uint32_t)cj;
+      const bool in = ((A >> j) & 1u) != 0u;
+      uint32_t same = 0u;           // the current owner of the same cell, if any (at most one)
+      float r_owner = 2.0f;
 #pragma unroll
-        for (int k = 1; k < j; ++k) {
-          if (!placed && ((owners >> k) & 1u) && cell[k] == cell[j]) {
-            if (rhat[j] < rhat[k]) owners = (owners & ~(1u << k)) | (1u << j);
-            placed = true;
-          }
-        }
-        if (!placed && rhat[j] < 1.0f) owners |= 1u << j;   // an empty cell holds 1.0
+      for (int k = 1; k < j; ++k) {
+        const bool hit = ((owners >> k) & 1u) != 0u && cell[k] == cell[j];
+        same |= (hit ? 1u : 0u) << k;
+        r_owner = hit ? rhat[k] : r_owner;
       }
+      const bool wins = in && (same ? rhat[j] < r_owner : rhat[j] < 1.0f);   // an empty cell holds 1.0
+      owners = wins ? ((owners & ~same) | (1u << j)) : owners;
     }
   }
+  TE_ESTAMP(5, 0);
   // ---- level5: what this step's stacked observation may look at, BEFORE anything respawns (te_stacked.hpp SnapRows)
   if (p.snap && valid) {
     const SnapRows sr{D, P};
@@ -302,16 +321,13 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     if (o.term.inertial) inertial_row(o.term.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, px[0], py[0], pz[0], ag, mun[0], lf[0], step);
     if (o.term.last_action) reinterpret_cast<float4*>(o.term.last_action)[env] = act;
   }
-  // terminal LIDAR tiles: ones by the whole wave, env by env (rare), drained before any patch lands on them
+  // terminal LIDAR tiles: ones by the whole wave, env by env (rare).  The patches below come from the SAME wave, later in program
+  // order: the stores of one wave to one address are performed in issue order, so nothing has to be drained in between
   if (o.term.lidar) {
-    unsigned long long tb = __ballot(to_terminal);
-    if (tb) {
-      for (; tb; tb &= tb - 1) {
-        const int l = __ffsll((long long)tb) - 1;
-        float* tile = o.term.lidar + (size_t)(blockIdx.x * 64 + l) * TE_OBS_LIDAR_WORDS;
-        for (int e = lane; e < TE_OBS_LIDAR_WORDS; e += 64) tile[e] = 1.0f;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (unsigned long long tb = __ballot(to_terminal); tb; tb &= tb - 1) {
+      const int l = __ffsll((long long)tb) - 1;
+      float* tile = o.term.lidar + (size_t)(blockIdx.x * 64 + l) * TE_OBS_LIDAR_WORDS;
+      for (int e = lane; e < TE_OBS_LIDAR_WORDS; e += 64) tile[e] = 1.0f;
     }
   }
   // patch the hit cells into the background the sub-step kernel's fill waves wrote (lidar_math.py:305: flag = type / 5;
@@ -331,6 +347,50 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     }
   }
 
+  // compute_reward (:423-515); Evaluation_Task.compute_reward returns 0 (evaluation_task.py:508-515)
+  float reward = 0.0f, cur_dist = last_dist;
+  if (!c.evaluation) {
+    float gs[3];
+    gun_state(c, mun[0], lf[0], step, max_munition_of(c, 0), gs);
+    const float dist_origin = fnorm(apos);
+    int ally = -1;  // identify_closest_ally (offsets_handler.py:167-190)
+    if ((S & 1u) && __popc(S & pur_bits) > 1) {
+      float bd = 0.0f;
+#pragma unroll
+      for (int a = 1; a < PM; ++a) {
+        if (a < P && ((S >> a) & 1u)) {
+          const float d = fdist(V3{px[a], py[a], pz[a]}, apos);
+          if (ally < 0 || d < bd) { ally = a; bd = d; }
+        }
+      }
+    }
+    int target = -1;
+#pragma unroll
+    for (int q = 0; q < PM; ++q) if (q == (ally < 0 ? 0 : ally) && ((S >> q) & 1u)) target = tgt[q];
+    const V3 tp = target >= 0 ? pos_of(target) : V3{0.0f, 0.0f, 0.0f};
+    cur_dist = fdist(apos, tp);
+    const bool ready = gs[2] == 1.0f || gs[0] == 0.0f;
+    float bonus = 0.0f, penalty = 0.0f;
+    if (0.01f < last_dist - cur_dist && ready) bonus += c.approach_bonus_gain * fnorm(V3{ag[3], ag[4], ag[5]});
+    const float score = ready ? -cur_dist : cur_dist * (2.0f * gs[1] - 1.0f);
+    if (agent_shots > 0 || agent_suicided > 0) bonus += (float)(agent_shots + agent_suicided) * 1000.0f;
+    if (ally_shots > 0 || pursuer_suicided > 0) bonus += 0.5f * (float)(ally_shots + pursuer_suicided) * 1000.0f;
+    else if (exploded > 0) penalty += 1000.0f * (float)exploded;
+    if (apos.z < -5.0f) penalty += (-5.0f - apos.z) * 1000.0f;
+    if (zone & pur_bits) penalty += 1000.0f;
+    if (dist_origin > c.born_radius - 2.0f) penalty += dist_origin - c.born_radius - 2.0f;  // literal (SURVEY.md C8)
+    reward = score + bonus - penalty;
+  }
+  if (valid) {
+    if (!c.evaluation) stef(TE_E_LAST_DIST, cur_dist);
+    ste(TE_E_AGENT_KILLS, (uint32_t)agent_kills); ste(TE_E_ALLIES_KILLS, (uint32_t)allies_kills); ste(TE_E_DEADS, (uint32_t)deads);
+    if (agent_shots + ally_shots > 0) ste(TE_E_MAX_STEP, (uint32_t)max_step);
+    o.reward[env] = reward;
+    o.done[env] = term ? 1 : 0;
+    reinterpret_cast<int4*>(o.info)[env] = make_int4(agent_kills, allies_kills, deads, round);
+  }
+
+  TE_ESTAMP(6, 0);
   // ---- on_step_end (:321-333): next wave when this one is cleared and a pursuer is alive; SB3 auto-reset -------------------
   uint32_t task = 0u;   // round | reset << 8: the slots of this env have to be respawned
   uint32_t snap_mask = S;
@@ -342,18 +402,18 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   if (valid && !term && armed_invaders == 0 && armed_pursuers > 0) {
     round = round + (round < c.n_rounds ? 1 : c.n_rounds);  // advance_round (:155-175)
     snap_mask = mask_after_spawn(round, false);
-    g.esi(TE_E_ROUND, round); g.esi(TE_E_SNAP_MASK, (int)snap_mask);
+    ste(TE_E_ROUND, (uint32_t)round); ste(TE_E_SNAP_MASK, snap_mask);
     task = (uint32_t)round;
   }
   if (to_terminal) {  // Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146): the env record here, the slots below
     episode += 1u; step = 0; max_step = c.max_step; round = 1;
     snap_mask = mask_after_spawn(1, true);
-    g.esi(TE_E_EPISODE, (int)episode); g.esi(TE_E_STEP, 0); g.esi(TE_E_MAX_STEP, c.max_step); g.esi(TE_E_ROUND, 1);
-    g.esi(TE_E_AGENT_KILLS, 0); g.esi(TE_E_ALLIES_KILLS, 0); g.esi(TE_E_DEADS, 0);
-    g.esf(TE_E_LAST_DIST, c.dome_radius);
+    ste(TE_E_EPISODE, episode); ste(TE_E_STEP, 0u); ste(TE_E_MAX_STEP, (uint32_t)c.max_step); ste(TE_E_ROUND, 1u);
+    ste(TE_E_AGENT_KILLS, 0u); ste(TE_E_ALLIES_KILLS, 0u); ste(TE_E_DEADS, 0u);
+    stef(TE_E_LAST_DIST, c.dome_radius);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) g.esf(TE_E_LAST_ACTION + k, 0.0f);
-    g.esi(TE_E_SNAP_MASK, (int)snap_mask);
+    for (int k = 0; k < 4; ++k) ste(TE_E_LAST_ACTION + k, 0u);
+    ste(TE_E_SNAP_MASK, snap_mask);
     act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
     for (int k = 0; k < 9; ++k) ag[k] = 0.0f;
@@ -367,14 +427,17 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
       const int l = __ffsll((long long)sb) - 1;
       const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)task, l);
       const uint32_t ep = (uint32_t)__builtin_amdgcn_readlane((int)episode, l);
+      const uint32_t armed_l = (uint32_t)__builtin_amdgcn_readlane((int)A, l);   // the env's flags after the engagement
       const bool reset = (t >> 8) != 0u;
       if (lane < D) {
         const GView gv{p.dstate, p.estate, D, p.Npad, (int)(blockIdx.x * 64 + l), P};
         V3 w{0.0f, 0.0f, 0.0f};
-        const bool placed = spawn_slot_at(c, gv, lane, (int)(t & 0xFFu), ep, reset, w);
+        const bool placed = spawn_slot_at(c, gv, lane, (int)(t & 0xFFu), ep, reset, ((armed_l >> lane) & 1u) != 0u, w);
         xs[lane][0] = w.x; xs[lane][1] = w.y; xs[lane][2] = w.z; xs[lane][3] = placed ? 1.0f : 0.0f;
       }
-      __syncthreads();  // single-wave workgroup: orders the LDS hand-over, waits for nobody
+      // single-wave workgroup: the LDS operations of one wave execute in order; only the compiler and the LDS counter have to be
+      // told (a __syncthreads() would also drain every outstanding global store of the wave: several microseconds here)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == l) {
 #pragma unroll
         for (int s = 0; s < DM; ++s)
@@ -386,14 +449,22 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
             if (q < P) { mun[q] = max_munition_of(c, q); lf[q] = -c.cooldown_steps; fx[q] = px[q]; fy[q] = py[q]; fz[q] = pz[q]; }
         }
       }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
+  TE_ESTAMP(7, 0);
   // ---- the observation of the state the step leaves (post-reset values for an auto-reset env)
-  if (valid) {
-    if (o.obs.inertial) inertial_row(o.obs.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, px[0], py[0], pz[0], ag, mun[0], lf[0], step);
-    if (o.obs.last_action) reinterpret_cast<float4*>(o.obs.last_action)[env] = act;
+  if (o.obs.inertial) {
+    inertial_row(rows + lane * TE_OBS_INERTIAL_WORDS, px[0], py[0], pz[0], ag, mun[0], lf[0], step);   // stride 15: conflict-free
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int n_out = min(64, p.N - (int)blockIdx.x * 64) * TE_OBS_INERTIAL_WORDS;
+    float* dst = o.obs.inertial + (size_t)blockIdx.x * 64 * TE_OBS_INERTIAL_WORDS;
+#pragma unroll
+    for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k)
+      if (k * 64 + lane < n_out) dst[k * 64 + lane] = rows[k * 64 + lane];
   }
+  if (valid && o.obs.last_action) reinterpret_cast<float4*>(o.obs.last_action)[env] = act;
+  TE_ESTAMP(8, 0);
   // ---- the pursuers' positions the invaders steer at during the next sub-step launch (TE_X_REF), and the scripted allies'
   // commands of the next step (Task.on_step_start -> LoyalWingmanBehaviorTree.update, loyalwingman_navigator.py:238-352)
   if (valid) {
@@ -402,7 +473,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
 #pragma unroll
     for (int q = 0; q < PM; ++q) {
       if (q < P) {
-        g.sf(TE_X_REF + 0, q, px[q]); g.sf(TE_X_REF + 1, q, py[q]); g.sf(TE_X_REF + 2, q, pz[q]);
+        stf(TE_X_REF + 0, q, px[q]); stf(TE_X_REF + 1, q, py[q]); stf(TE_X_REF + 2, q, pz[q]);
         if ((q > 0 || c.evaluation) && ((armed_post >> q) & 1u) && q != first_skipped) {
           float out[3] = {0.0f, 0.0f, 0.0f};
           const bool ext = driven_externally(c, q);
@@ -415,7 +486,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
                 for (int j = 1; j < DM; ++j) {
                   if (j >= P && ((snap_mask >> j) & 1u)) {
                     const V3 pj{px[j], py[j], pz[j]};
-                    const float d = dist(me, pj);
+                    const float d = fdist(me, pj);
                     if (t < 0 || d < bd) { t = j; bd = d; tp = pj; }
                   }
                 }
@@ -425,11 +496,12 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
           } else if (ext || c.ally_policy != TE_ALLY_FROZEN) {  // nobody / the caller's policy: the set-point persists
             out[0] = g.gf(TE_D_SETPOINT + 0, q); out[1] = g.gf(TE_D_SETPOINT + 1, q); out[2] = g.gf(TE_D_SETPOINT + 3, q);
           }
-          g.sf(TE_X_CMD + 0, q, out[0]); g.sf(TE_X_CMD + 1, q, out[1]); g.sf(TE_X_CMD + 2, q, out[2]);
+          stf(TE_X_CMD + 0, q, out[0]); stf(TE_X_CMD + 1, q, out[1]); stf(TE_X_CMD + 2, q, out[2]);
         }
       }
     }
   }
+  TE_ESTAMP(9, 0);
   // ---- what the next sub-step launch has to fly for this chunk (post-spawn flags)
   {
     uint32_t dense = 0u; int n = 0;
@@ -437,6 +509,8 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     for (int s = 0; s < D; ++s) plan_slot_l4<void>(items, p.dense_min, lane, s, valid && ((armed_post >> s) & 1u), dense, n);
     if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = (uint32_t)n; }
   }
+  TE_ESTAMP(10, 0);
+  TE_ESTAMP(11, 1);   // ... and once every store has been acknowledged
 }
 
 }  // namespace te
