@@ -32,6 +32,7 @@ struct Derived {
   // PID gains with the controller period folded in: ki * T and kd / T
   float lv_kiT[2], lv_kdT[2], av_kiT[3], av_kdT[3], zv_kiT, zv_kdT;
   float half_dt, quarter_dt2, noise_m2ln2;
+  int ctrl_ratio;  // physics sub-steps per controller period (control_dt / physics_dt = 2): only read when cfg.control_every_substep == 0
   float ground_rest;  // z of a hull resting on the ground plane (ground_z + hull_half_height); used when cfg.ground_contact  // dt/2, dt^2/4, -2 ln 2 * noise_ratio^2 (Box-Muller radius incl. the noise gain)
 };
 constexpr int kMixedWaves = 2, kMixedCap = 64 * kMixedWaves;  // mixed waves per chunk; a slot that would overflow the list flies densely
@@ -252,6 +253,7 @@ struct Body {
   V3 pos; Q4 q; V3 vel; V3 wb;   // wb: angular velocity in BODY components (see integrate())
   float thr[4];
   float av_i[3], av_e[3], lv_i[2], lv_e[2], zv_i, zv_e;
+  float pwm[4];  // QuadX.pwm between two controller updates: only live in the cfg.control_every_substep == 0 instantiation
   // IMU read (lagged observation)
   V3 o_pos, o_eul, o_vel, o_rate;
 };
@@ -274,6 +276,8 @@ __host__ __device__ inline Derived derive(const te_config& c) {
   d.half_dt = 0.5f * c.physics_dt; d.quarter_dt2 = 0.25f * c.physics_dt * c.physics_dt;
   d.noise_m2ln2 = -2.0f * 0.69314718056f * q.noise_ratio * q.noise_ratio;
   d.ground_rest = c.ground_z + c.hull_half_height;
+  d.ctrl_ratio = (int)(c.control_dt / c.physics_dt + 0.5f);
+  if (d.ctrl_ratio < 1) d.ctrl_ratio = 1;
   return d;
 }
 
@@ -320,7 +324,10 @@ TE_DEV void motor_noise_from(uint32_t a, uint32_t b, float m2ln2_gain2, float nz
 //    right of q;
 //  * cos/sin(yaw) come from the first column of R instead of sincos(atan2(.));
 //  * sin/cos of the half rotation angle (< 0.5 rad per 1/240 s for any sane rate) by Taylor polynomials.
-template <bool MODE7, bool CAPTURE, bool NOISE, bool GROUND = false>
+// CTRL: 1 = the controller runs in this sub-step and its pwm is used at once (the reference's loop: update_control on every physics
+// sub-step, level4_simulation.py:92-94); for cfg.control_every_substep == 0 (PyFlyt's own 120 Hz): 0 = a controller sub-step whose
+// pwm is also kept in b.pwm, 2 = a coasting sub-step that feeds the motors b.pwm again (no IMU angles, no PIDs, unless CAPTURE)
+template <bool MODE7, bool CAPTURE, bool NOISE, bool GROUND = false, int CTRL = 1>
 TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float sp[4], uint32_t noise_a, uint32_t noise_b,
                     V3& pend_f, V3& pend_t) {
   const te_quad_params& qp = c.quad;
@@ -329,9 +336,11 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
   // ---- IMU (imu.py:27-41)
   V3 vb = mulT(R, b.vel);
   float sarg = -R.m20;
-  float roll, pitch, cyaw, syaw;
+  float roll = 0.0f, pitch = 0.0f, cyaw = 1.0f, syaw = 0.0f;
   bool guard = fabsf(sarg) >= 0.99999f;
-  if (!guard) {
+  if (CTRL == 2 && !CAPTURE) {
+    // coasting sub-step: nobody looks at the angles
+  } else if (!guard) {
     roll = fast_atan2(R.m21, R.m22);
     pitch = fast_asin(sarg);
     float inv = rsq(R.m00 * R.m00 + R.m10 * R.m10);
@@ -348,6 +357,11 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
     b.o_eul = guard ? euler_of(b.q) : V3{roll, pitch, fast_atan2(R.m10, R.m00)};
   }
   // ---- controller (PyFlyt QuadX.update_control; every sub-step, PID period control_dt)
+  float pwm[4];
+  if (CTRL == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pwm[i] = b.pwm[i];
+  } else {
   float a0 = sp[0], a1 = sp[1], zc = sp[3];
   if (MODE7) {
     a0 = clampf(qp.lin_pos_kp[0] * (a0 - b.pos.x), -qp.lin_pos_lim[0], qp.lin_pos_lim[0]);
@@ -364,7 +378,7 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
   float t2 = pid(qp.ang_vel_kp[2], k.av_kiT[2], k.av_kdT[2], qp.ang_vel_lim[2], sp[2] - b.wb.z, b.av_i[2], b.av_e[2]);
   float th = pid(qp.z_vel_kp, k.zv_kiT, k.zv_kdT, qp.z_vel_lim, zc - vb.z, b.zv_i, b.zv_e);
   th = clampf(th, 0.0f, 1.0f);
-  float pwm[4] = {-t0 - t1 + t2 + th, t0 + t1 + t2 + th, -t0 + t1 - t2 + th, t0 - t1 - t2 + th};
+  pwm[0] = -t0 - t1 + t2 + th; pwm[1] = t0 + t1 + t2 + th; pwm[2] = -t0 + t1 - t2 + th; pwm[3] = t0 - t1 - t2 + th;
   float hi = fmaxf(fmaxf(pwm[0], pwm[1]), fmaxf(pwm[2], pwm[3]));
   if (__builtin_amdgcn_ballot_w64(hi > 1.0f) != 0ull && hi > 1.0f) {  // wave-uniform test first: saturation is rare
     float s = rcp(hi);
@@ -376,6 +390,11 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
     float f = (k.pwm_floor - lo) * rcp(1.0f - lo);
 #pragma unroll
     for (int i = 0; i < 4; ++i) pwm[i] += (1.0f - pwm[i]) * f;
+  }
+  if (CTRL == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b.pwm[i] = pwm[i];
+  }
   }
   // ---- motors (first-order lag, multiplicative noise, thrust/torque ~ rpm^2) + drag
   float T_[4], nz[4] = {0.0f, 0.0f, 0.0f, 0.0f};

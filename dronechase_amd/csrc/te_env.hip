@@ -72,7 +72,8 @@ struct NavView {
 // wave-uniform and the lanes are the 64 envs of a chunk; in a MIXED wave every lane carries its own (env, slot) item of
 // the chunk's sparsely armed slots (Params::mixed_items), so `slot` is a per-lane value: the buffer addressing
 // (SlotLane: per-lane byte offset + scalar plane offset) is the same for both.
-template <int FAMILY, bool NOISE, bool MIXED>
+// CES = cfg.control_every_substep (the reference's 240 Hz controller calls); false = PyFlyt-native 120 Hz
+template <int FAMILY, bool NOISE, bool MIXED, bool CES = true>
 TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, int env, bool valid) {
   const int D = p.D;
   const SlotLane P(p.dstate, p.estate, (uint32_t)D, (uint32_t)p.Npad, (uint32_t)slot, (uint32_t)env,
@@ -176,15 +177,35 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
       na = bits.x; nb = bits.y; held_a = bits.z; held_b = bits.w;                     \
     } else { na = held_a; nb = held_b; }                                              \
   }
+  if (!CES) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b.pwm[i] = 0.0f;   // sub-step 0 is always a controller sub-step
+  }
   for (int s = 0; s < n_plain; ++s) {
     TE_DRAW(s)
-    if (mode7) substep<true, false, NOISE>(c, kd, b, sp, na, nb, pf, pt);  // wave-uniform: slot is per wave
-    else substep<false, false, NOISE, kGround>(c, kd, b, sp, na, nb, pf, pt);
+    if (CES) {
+      if (mode7) substep<true, false, NOISE>(c, kd, b, sp, na, nb, pf, pt);  // wave-uniform: slot is per wave
+      else substep<false, false, NOISE, kGround>(c, kd, b, sp, na, nb, pf, pt);
+    } else if (s % kd.ctrl_ratio == 0) {   // wave-uniform
+      if (mode7) substep<true, false, NOISE, false, 0>(c, kd, b, sp, na, nb, pf, pt);
+      else substep<false, false, NOISE, kGround, 0>(c, kd, b, sp, na, nb, pf, pt);
+    } else {
+      if (mode7) substep<true, false, NOISE, false, 2>(c, kd, b, sp, na, nb, pf, pt);
+      else substep<false, false, NOISE, kGround, 2>(c, kd, b, sp, na, nb, pf, pt);
+    }
   }
   if (c.observe_lag) {
     TE_DRAW(S - 1)
-    if (mode7) substep<true, true, NOISE>(c, kd, b, sp, na, nb, pf, pt);
-    else substep<false, true, NOISE, kGround>(c, kd, b, sp, na, nb, pf, pt);
+    if (CES) {
+      if (mode7) substep<true, true, NOISE>(c, kd, b, sp, na, nb, pf, pt);
+      else substep<false, true, NOISE, kGround>(c, kd, b, sp, na, nb, pf, pt);
+    } else if ((S - 1) % kd.ctrl_ratio == 0) {
+      if (mode7) substep<true, true, NOISE, false, 0>(c, kd, b, sp, na, nb, pf, pt);
+      else substep<false, true, NOISE, kGround, 0>(c, kd, b, sp, na, nb, pf, pt);
+    } else {
+      if (mode7) substep<true, true, NOISE, false, 2>(c, kd, b, sp, na, nb, pf, pt);
+      else substep<false, true, NOISE, kGround, 2>(c, kd, b, sp, na, nb, pf, pt);
+    }
   }
 #undef TE_DRAW
 
@@ -215,7 +236,7 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
   }
 }
 
-template <int FAMILY, bool NOISE, bool FILL>
+template <int FAMILY, bool NOISE, bool FILL, bool CES = true>
 __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params p, const float* __restrict__ actions, FillJob fill) {
   int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (unsigned)TE_K1_BLOCK + threadIdx.x) >> 6));
   const int lane = threadIdx.x & 63;
@@ -245,7 +266,7 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
     const int i = m * 64 + lane;
     const bool valid = i < count;
     const uint32_t item = valid ? (uint32_t)p.mixed_items[(size_t)chunk * kMixedCap + i] : 0u;
-    fly<FAMILY, NOISE, true>(p, actions, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid);
+    fly<FAMILY, NOISE, true, CES>(p, actions, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid);
     return;
   }
   if (wave >= n_head) wave -= n_mixed;
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   const uint32_t chunk_mask = __builtin_amdgcn_readfirstlane(((const uint32_t* __restrict__)p.slot_mask)[chunk]);
   if (!((chunk_mask >> slot) & 1u)) return;
   const int env = chunk * 64 + lane;  // planes are padded to Npad: lanes beyond N still read in bounds
-  fly<FAMILY, NOISE, false>(p, actions, slot, env, env < p.N);
+  fly<FAMILY, NOISE, false, CES>(p, actions, slot, env, env < p.N);
 }
 
 // ============================================================================================
@@ -812,7 +833,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->stacked_obs && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: stacked_obs needs a level4-family task");
   if (cfg->task == TE_TASK_STAGE01 && !(cfg->n_pursuers == 2 && cfg->n_invaders == 1)) return fail("te_create: stage01 is 2 pursuers + 1 invader");
   if (cfg->lidar_radius <= 0.0f || cfg->dome_radius <= 0.0f || cfg->max_speed <= 0.0f) return fail("te_create: radii / max_speed must be positive");
-  if (cfg->control_every_substep != 1) return fail("te_create: control_every_substep = 0 is not built yet");
+  if (cfg->control_every_substep != 0 && cfg->control_every_substep != 1) return fail("te_create: control_every_substep is 0 or 1");
   if (cfg->lidar_channels != TE_LIDAR_CHANNELS) return fail("te_create: lidar_channels must be 3 (2 is not built yet)");
   if (cfg->io_location != TE_IO_DEVICE) return fail("te_create: io_location = TE_IO_HOST is not built yet");
   if (cfg->drone_contact != 0) return fail("te_create: drone_contact is not built yet");
@@ -1063,8 +1084,10 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   launch_by_family(e->family, [&](auto fam) {
     constexpr int F = decltype(fam)::value;
     auto go = [&](auto noise_c, auto fill_c) {
-      hipLaunchKernelGGL((substeps_kernel<F, decltype(noise_c)::value, decltype(fill_c)::value>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p,
-                         actions, fill);
+      if (p.cfg.control_every_substep)
+        hipLaunchKernelGGL((substeps_kernel<F, decltype(noise_c)::value, decltype(fill_c)::value, true>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p, actions, fill);
+      else
+        hipLaunchKernelGGL((substeps_kernel<F, decltype(noise_c)::value, decltype(fill_c)::value, false>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p, actions, fill);
     };
     if (noise) { if (fill.lidar) go(std::true_type{}, std::true_type{}); else go(std::true_type{}, std::false_type{}); }
     else { if (fill.lidar) go(std::false_type{}, std::true_type{}); else go(std::false_type{}, std::false_type{}); }

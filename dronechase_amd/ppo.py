@@ -152,6 +152,15 @@ class PPO:
         if self.distributed:  # same initial weights on every rank
             for p in self.policy.parameters():
                 torch.distributed.broadcast(p.data, src=0)
+        # ONE gradient bucket: every parameter's .grad is a view of this flat buffer, so data-parallel training averages the
+        # gradients of a minibatch with a single all-reduce (RCCL over xGMI: a ring is per-link bound, 25 small collectives per
+        # minibatch would be latency-bound; the policy has ~0.3 M parameters = 1.2 MB, one bucket)
+        params = [p for p in self.policy.parameters() if p.requires_grad]
+        self._flat_grad = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=self.device)
+        off = 0
+        for p in params:
+            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
         env.reset()
         self.direct = env.N % 2 == 0   # slot t of the LIDAR buffer starts on a 16-byte boundary (4 056 bytes per env)
         self._obs = None               # set by the first collect(): te_observe of the reset state
@@ -279,14 +288,11 @@ class PPO:
                 vl = torch.nn.functional.mse_loss(v, ret[idx])
                 ent = dist.entropy().sum(-1).mean()
                 loss = pg + c.vf_coef * vl - c.ent_coef * ent
-                self.opt.zero_grad(set_to_none=True)
+                self._flat_grad.zero_()          # the parameters' .grad are views of it: backward accumulates in place
                 loss.backward()
-                if self.distributed:
-                    ws = torch.distributed.get_world_size()
-                    for p in self.policy.parameters():
-                        if p.grad is not None:
-                            torch.distributed.all_reduce(p.grad)
-                            p.grad.div_(ws)
+                if self.distributed:             # the system's only collective: mean gradient over the ranks, one bucket
+                    torch.distributed.all_reduce(self._flat_grad)
+                    self._flat_grad.div_(torch.distributed.get_world_size())
                 nn.utils.clip_grad_norm_(self.policy.parameters(), c.max_grad_norm)
                 self.opt.step()
                 with torch.no_grad():

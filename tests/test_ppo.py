@@ -76,3 +76,101 @@ def test_short_training_run_on_device(use_graph):
     steps = w[512 * env.D * K.DRONE_WORDS:].view(512, K.ENV_WORDS)[:, K.E["STEP"]]
     assert int(steps.max()) <= 2 * 16 and int(steps.max()) >= 16
     env.close()
+
+
+class _StubEnv:
+    """What PPO needs of an environment to build its buffers (no stepping): used where there is no GPU."""
+
+    def __init__(self, n):
+        import torch
+        self.device, self.N = torch.device("cpu"), n
+        self.lidar = torch.ones((n, 3, 13, 26)); self.inertial = torch.zeros((n, 15)); self.cfg = None
+
+    def reset(self):
+        return None
+
+
+def _ppo_rank(rank, world, port, out_dir):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from dronechase_amd.ppo import PPO, PPOConfig
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+
+    def fill(ppo, seed):   # a synthetic rollout, different on every rank (each rank owns its own env shard)
+        g = torch.Generator().manual_seed(seed)
+        b = ppo.buf
+        b.obs["lidar"].copy_(torch.rand(b.obs["lidar"].shape, generator=g)); b.obs["inertial_data"].copy_(torch.rand(b.obs["inertial_data"].shape, generator=g) * 2 - 1)
+        b.obs["last_action"].copy_(torch.rand(b.obs["last_action"].shape, generator=g))
+        b.actions.copy_(torch.randn(b.actions.shape, generator=g)); b.logp.copy_(-torch.rand(b.logp.shape, generator=g) * 4)
+        b.values.copy_(torch.randn(b.values.shape, generator=g)); b.rewards.copy_(torch.randn(b.rewards.shape, generator=g))
+        b.dones.copy_((torch.rand(b.dones.shape, generator=g) < 0.1).float())
+        b.finish(torch.randn(b.rewards.shape[1], generator=g), 0.99, 0.95)
+
+    cfg = PPOConfig(n_steps=4, batch_size=32, n_epochs=2, use_graph=False)
+    # (1) what a rank would learn on its own data alone (no process group yet)
+    alone = PPO(_StubEnv(16), cfg, seed=5)
+    fill(alone, 100 + rank)
+    torch.manual_seed(7); alone.update()
+    # (2) the data-parallel run: rank-dependent initial weights on purpose, PPO must broadcast rank 0's
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ppo = PPO(_StubEnv(16), cfg, seed=5 + rank)
+    assert ppo.distributed
+    init = torch.cat([p.detach().flatten() for p in ppo.policy.parameters()]).clone()
+    fill(ppo, 100 + rank)
+    torch.manual_seed(7); stats = ppo.update()
+    flat = torch.cat([p.detach().flatten() for p in ppo.policy.parameters()])
+    bucket = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(bucket, flat)
+    inits = [torch.empty_like(init) for _ in range(world)]
+    dist.all_gather(inits, init)
+    torch.save(dict(params=bucket, inits=inits, alone=torch.cat([p.detach().flatten() for p in alone.policy.parameters()]), stats=stats,
+                    views=all(p.grad.data_ptr() >= ppo._flat_grad.data_ptr() for p in ppo.policy.parameters())), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_update_over_gloo(tmp_path):
+    """BASELINE config 5's only collective, on the CPU with two gloo ranks: PPO.update() on different rollouts per rank must leave
+    IDENTICAL parameters on both ranks (initial broadcast + one bucketed gradient all-reduce per minibatch), different from the
+    initial ones and different from what either rank learns alone."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.start_processes(_ppo_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in (0, 1))
+    assert torch.equal(r0["inits"][0], r0["inits"][1])                      # rank 0's weights everywhere before the first step
+    assert torch.equal(r0["params"][0], r0["params"][1]) and torch.equal(r0["params"][0], r1["params"][1])   # ... and after the update
+    assert not torch.equal(r0["params"][0], r0["inits"][0])
+    assert not torch.allclose(r0["params"][0], r0["alone"]) and not torch.allclose(r1["params"][1], r1["alone"])
+    assert r0["views"] and all(np.isfinite(v) for v in r0["stats"].values())
+
+
+@pytest.mark.gpu
+def test_training_run_at_16k_envs():
+    """Config 5 at a size that means something on one GPU: 16 384 stage03 envs, 32-step rollouts captured in a HIP graph (1.1 GB of
+    observations resident in HBM), two updates of 16 minibatches."""
+    import time
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    from dronechase_amd.ppo import PPO, PPOConfig
+    N = 16384
+    env = BatchedEnv(default_config("stage03", n_envs=N), "cuda:0")
+    ppo = PPO(env, PPOConfig(n_steps=32, batch_size=32768, n_epochs=1, use_graph=True), seed=3)
+    assert ppo.buf.bytes() > 2 ** 30
+    logs = []
+    ppo.collect()                      # captures the graph
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ppo.learn(ppo.num_timesteps + 2 * 32 * N, log=logs.append)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    assert len(logs) == 2 and all(np.isfinite(v) for e in logs for v in e.values())
+    assert logs[-1]["episodes_finished"] >= 0 and 0.0 <= logs[-1]["clip_frac"] <= 1.0
+    print(f"PPO at {N} envs: {2 * 32 * N / dt / 1e6:.2f} M env-steps/s collect + update")
+    env.close()
