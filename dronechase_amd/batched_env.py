@@ -32,7 +32,7 @@ class BatchedEnv:
         _lib.check(self.L.te_create(C.byref(self.cfg), index, C.byref(self._h)), "te_create")
         N, dev = self.N, self.device
         f32 = dict(dtype=torch.float32, device=dev)
-        self.lidar = torch.empty((N, K.LIDAR_CHANNELS, K.LIDAR_NTHETA, K.LIDAR_NPHI), **f32)
+        self.lidar = torch.empty((N, int(cfg.lidar_channels), K.LIDAR_NTHETA, K.LIDAR_NPHI), **f32)
         self.inertial = torch.empty((N, K.OBS_INERTIAL_WORDS), **f32)
         self.last_action = torch.empty((N, 4), **f32)
         self.t_lidar = torch.zeros_like(self.lidar)

@@ -164,7 +164,7 @@ TE_API int te_config_default(te_config* c, int32_t task) {
 TE_API int te_algorithmic_bytes_per_env_step(const te_config* c, size_t* out) {
   if (!c || !out) return 1;
   size_t D = (size_t)(c->n_pursuers + c->n_invaders);
-  *out = D * 2 * 176 + 2 * 40 + 16 + ((size_t)TE_LIDAR_CHANNELS * TE_LIDAR_CELLS * 4 + 15 * 4 + 4 * 4 + 4 + 4);
+  *out = D * 2 * 176 + 2 * 40 + 16 + ((size_t)(c->lidar_channels == 2 ? 2 : TE_LIDAR_CHANNELS) * TE_LIDAR_CELLS * 4 + 15 * 4 + 4 * 4 + 4 + 4);
   if (c->stacked_obs) {  /* level5: 6 spheres + mask instead of 1; one ring entry written per wingman, <= 4 read */
     size_t P = (size_t)c->n_pursuers, entry = (size_t)TE_RING_ENTRY_WORDS(D) * 4;
     *out += (size_t)(TE_STACK_SPHERES - 1) * TE_OBS_LIDAR_WORDS * 4 + TE_STACK_SPHERES + P * entry + 4 * entry;

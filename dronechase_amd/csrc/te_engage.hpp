@@ -326,8 +326,8 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   if (o.term.lidar) {
     for (unsigned long long tb = __ballot(to_terminal); tb; tb &= tb - 1) {
       const int l = __ffsll((long long)tb) - 1;
-      float* tile = o.term.lidar + (size_t)(blockIdx.x * 64 + l) * TE_OBS_LIDAR_WORDS;
-      for (int e = lane; e < TE_OBS_LIDAR_WORDS; e += 64) tile[e] = 1.0f;
+      float* tile = o.term.lidar + (size_t)(blockIdx.x * 64 + l) * lidar_words(c);
+      for (int e = lane; e < lidar_words(c); e += 64) tile[e] = 1.0f;
     }
   }
   // patch the hit cells into the background the sub-step kernel's fill waves wrote (lidar_math.py:305: flag = type / 5;
@@ -335,13 +335,14 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   {
     float* dst = to_terminal ? o.term.lidar : o.obs.lidar;
     if (valid && dst) {
-      dst += (size_t)env * TE_OBS_LIDAR_WORDS;
+      dst += (size_t)env * lidar_words(c);
+      const bool time_plane = c.lidar_channels != 2;
 #pragma unroll
       for (int j = 1; j < DM; ++j) {
         if ((owners >> j) & 1u) {
           dst[cell[j]] = rhat[j];
           dst[TE_LIDAR_CELLS + cell[j]] = (float)(j < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
-          dst[2 * TE_LIDAR_CELLS + cell[j]] = 0.1f;
+          if (time_plane) dst[2 * TE_LIDAR_CELLS + cell[j]] = 0.1f;
         }
       }
     }

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(THREADS) void engage_observe_kernel(Params p, const
   // terminal tiles of auto-reset envs (rare, block-uniform test): ones, drained, then patched
   const bool lane_done = threadIdx.x < kEPB && sm[r.done() * kEPB + threadIdx.x] != 0u;
   if (o.term.lidar && __syncthreads_or(lane_done ? 1 : 0)) {
-    stream_terminal_ones(sm, r, o.term.lidar, env0, nvalid);
+    stream_terminal_ones(p.cfg, sm, r, o.term.lidar, env0, nvalid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -549,8 +549,8 @@ __global__ __launch_bounds__(256) void observe_ally_kernel(Params p, int me, flo
     }
   }
   if (lidar && w == nfeat) {  // the chunk's tile: 64 * 1014 floats, 16-byte aligned; non-temporal like the sub-step kernel's background
-    float* tile = lidar + (size_t)env0 * TE_OBS_LIDAR_WORDS;
-    const int total = nvalid * TE_OBS_LIDAR_WORDS, quads = total >> 2;
+    float* tile = lidar + (size_t)env0 * lidar_words(c);
+    const int total = nvalid * lidar_words(c), quads = total >> 2;
     for (int qi = l; qi < quads; qi += kEPB) TE_FILL_STORE(reinterpret_cast<float4*>(tile) + qi);
     for (int f = (quads << 2) + l; f < total; f += kEPB) tile[f] = 1.0f;
   }
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void observe_ally_kernel(Params p, int me, flo
   if (!sees) return;
   // owner of a cell = smallest range, the earlier slot on ties (strict '<' in slot order, lidar_math.py:262-311); a
   // feature clipped to 1.0 never enters an empty cell
-  float* base = lidar + (size_t)(env0 + l) * TE_OBS_LIDAR_WORDS;
+  float* base = lidar + (size_t)(env0 + l) * lidar_words(c);
   for (int j = w; j < D; j += nw) {
     const uint32_t cell = s_cell[j * kEPB + l];
     const float rhat = s_rhat[j * kEPB + l];
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void observe_ally_kernel(Params p, int me, flo
     if (!owner) continue;
     base[cell] = rhat;
     base[TE_LIDAR_CELLS + cell] = (float)(j < c.n_pursuers ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
-    base[2 * TE_LIDAR_CELLS + cell] = 0.1f;
+    if (c.lidar_channels != 2) base[2 * TE_LIDAR_CELLS + cell] = 0.1f;
   }
 }
 // The same observation as two launches for full-size batches (48 us instead of 64 at 65 536 envs):
@@ -662,8 +662,9 @@ __global__ __launch_bounds__(256) void ally_patch_kernel(Params p, float* __rest
   if (env >= p.N) return;
   const uint32_t w = scratch[(size_t)(2 * j) * p.Npad + env];
   if (w == 0xFFFFFFFFu) return;
-  float* d = lidar + (size_t)env * TE_OBS_LIDAR_WORDS + (w & 0xFFFFu);
-  d[0] = __uint_as_float(scratch[(size_t)(2 * j + 1) * p.Npad + env]); d[TE_LIDAR_CELLS] = (float)(w >> 16) / 5.0f; d[2 * TE_LIDAR_CELLS] = 0.1f;
+  float* d = lidar + (size_t)env * lidar_words(p.cfg) + (w & 0xFFFFu);
+  d[0] = __uint_as_float(scratch[(size_t)(2 * j + 1) * p.Npad + env]); d[TE_LIDAR_CELLS] = (float)(w >> 16) / 5.0f;
+  if (p.cfg.lidar_channels != 2) d[2 * TE_LIDAR_CELLS] = 0.1f;
 }
 // exp05: pursuer.drive(action) of drive_lw_rl_agent (exp05_vFinal_task.py:255-260; quadcopter.py:379-413) for armed allies
 __global__ __launch_bounds__(256) void set_ally_actions_kernel(Params p, int me, const float* __restrict__ actions) {
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(256) void observe_kernel(Params p, ObsOut o) {
   const Rows r{p.D, p.cfg.n_pursuers};
   const int env0 = blockIdx.x * kEPB;
   const int nvalid = min(kEPB, p.N - env0);
-  if (o.lidar) stream_ones(o.lidar, env0, nvalid);
+  if (o.lidar) stream_ones(p.cfg, o.lidar, env0, nvalid);
   stage_block(p, sm, r, env0);
   __syncthreads();
   precompute_block(p.cfg, sm, r);
@@ -765,6 +766,14 @@ struct te_env {
                                // chunk); 0 = engage_observe_kernel (LDS phases): other shapes, stage01 / stage02, TE_ENGAGE=lds
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
   uint32_t* ally_scratch = nullptr;  // te_observe_wingman: owner planes between its two launches (te_create allocates them when a wingman is caller-driven)
+  // cfg.io_location == TE_IO_HOST: device staging of every I/O buffer of te_step / te_observe / te_reset / te_random_actions /
+  // te_get_state / te_set_state (one allocation, carved at 256-byte boundaries by te_create)
+  struct HostStage {
+    char* base = nullptr;
+    float *actions = nullptr, *lidar = nullptr, *inertial = nullptr, *last_action = nullptr, *reward = nullptr;
+    float *t_lidar = nullptr, *t_inertial = nullptr, *t_last_action = nullptr;
+    uint8_t *done = nullptr, *mask = nullptr; int32_t* info = nullptr; uint32_t* blob = nullptr;
+  } hs;
   int n_fill_waves = 256;  // fill waves of the sub-step kernel: one per CU of an MI355X; four per CU for the six-sphere background of
                            // level5, where ~9 flight waves per SIMD would leave one fill wave too small a share of the issue slots
                            // (605 -> 567 us/step; 512 / 1024 fill waves cost stage03 7 / 40 %); TE_FILL_WAVES overrides
@@ -809,6 +818,14 @@ static void launch_census(te_env* e, hipStream_t st) {
   });
 }
 
+
+// ---- cfg.io_location == TE_IO_HOST: the caller's pointers are HOST pointers (what an SB3 SubprocVecEnv-style caller holds).  Inputs
+// are copied to the staging buffers, the device entry point runs on them, outputs are copied back and the stream is drained: the
+// call returns with the host buffers filled.  The observation (4.1 KB per env) crosses PCIe every step: ~15 M env-steps/s at best.
+static bool host_io(const te_env* e) { return e && e->p.cfg.io_location == TE_IO_HOST; }
+#define TE_H2D(dst, src, bytes) do { if ((src) && (bytes)) TE_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
+#define TE_D2H(dst, src, bytes) do { if ((dst) && (bytes)) TE_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, st)); } while (0)
+
 extern "C" {
 
 __attribute__((visibility("default"))) const char* te_last_error(void) { return g_err.c_str(); }
@@ -834,8 +851,11 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->task == TE_TASK_STAGE01 && !(cfg->n_pursuers == 2 && cfg->n_invaders == 1)) return fail("te_create: stage01 is 2 pursuers + 1 invader");
   if (cfg->lidar_radius <= 0.0f || cfg->dome_radius <= 0.0f || cfg->max_speed <= 0.0f) return fail("te_create: radii / max_speed must be positive");
   if (cfg->control_every_substep != 0 && cfg->control_every_substep != 1) return fail("te_create: control_every_substep is 0 or 1");
-  if (cfg->lidar_channels != TE_LIDAR_CHANNELS) return fail("te_create: lidar_channels must be 3 (2 is not built yet)");
-  if (cfg->io_location != TE_IO_DEVICE) return fail("te_create: io_location = TE_IO_HOST is not built yet");
+  if (cfg->lidar_channels != 3 && cfg->lidar_channels != 2) return fail("te_create: lidar_channels is 3 (distance, flag, time) or 2 (distance, flag)");
+  if (cfg->lidar_channels == 2 && cfg->stacked_obs) return fail("te_create: the stacked observation (level5) always has 3 channels");
+  if (cfg->io_location != TE_IO_DEVICE && cfg->io_location != TE_IO_HOST) return fail("te_create: io_location is TE_IO_DEVICE or TE_IO_HOST");
+  if (cfg->io_location == TE_IO_HOST && (cfg->stacked_obs || cfg->ally_policy == TE_ALLY_EXTERNAL || ((uint32_t)cfg->evaluation >> 8) != 0u))
+    return fail("te_create: TE_IO_HOST serves te_reset / te_observe / te_step / te_random_actions / te_get_state / te_set_state; the stacked observation and caller-driven wingmen take device pointers");
   if (cfg->drone_contact != 0) return fail("te_create: drone_contact is not built yet");
   int ndev = 0;
   TE_HIP(hipGetDeviceCount(&ndev));
@@ -904,6 +924,19 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->ally_policy == TE_ALLY_EXTERNAL || ((uint32_t)cfg->evaluation >> 8) != 0u) {
     if (hipMalloc(&e->ally_scratch, (size_t)2 * D * e->p.Npad * 4) != hipSuccess) return bail("te_create: hipMalloc failed");
   }
+  if (cfg->io_location == TE_IO_HOST) {
+    const size_t N = (size_t)cfg->n_envs, lw = (size_t)lidar_words(*cfg) * 4;
+    const size_t blob = (N * ((size_t)D * TE_DRONE_WORDS + TE_ENV_WORDS)) * 4;
+    const size_t sizes[12] = {N * 16, N * lw, N * 60, N * 16, N * 4, N * lw, N * 60, N * 16, N, N, N * 16, blob};
+    size_t off[13]; off[0] = 0;
+    for (int k = 0; k < 12; ++k) off[k + 1] = off[k] + ((sizes[k] + 255) & ~(size_t)255);
+    if (hipMalloc(&e->hs.base, off[12]) != hipSuccess) return bail("te_create: hipMalloc failed (host I/O staging)");
+    char* b = e->hs.base;
+    e->hs.actions = (float*)(b + off[0]); e->hs.lidar = (float*)(b + off[1]); e->hs.inertial = (float*)(b + off[2]);
+    e->hs.last_action = (float*)(b + off[3]); e->hs.reward = (float*)(b + off[4]); e->hs.t_lidar = (float*)(b + off[5]);
+    e->hs.t_inertial = (float*)(b + off[6]); e->hs.t_last_action = (float*)(b + off[7]); e->hs.done = (uint8_t*)(b + off[8]);
+    e->hs.mask = (uint8_t*)(b + off[9]); e->hs.info = (int32_t*)(b + off[10]); e->hs.blob = (uint32_t*)(b + off[11]);
+  }
   e->p.entry_words = TE_RING_ENTRY_WORDS(D);
   if (cfg->stacked_obs) {
     e->stack_lds_bytes = (size_t)stack_lds_rows(D, cfg->n_pursuers) * kEPB * sizeof(uint32_t);
@@ -942,6 +975,7 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   (void)hipFree(e->p.dstate);
   (void)hipFree(e->p.estate);
   (void)hipFree(e->ally_scratch);
+  (void)hipFree(e->hs.base);
   (void)hipFree(e->p.slot_mask); (void)hipFree(e->p.mixed_count); (void)hipFree(e->p.mixed_items);
   (void)hipFree(e->p.stage_tab);
   if (e->p.snap) (void)hipFree(e->p.snap);
@@ -953,6 +987,11 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
 __attribute__((visibility("default"))) int te_reset(te_env* e, const uint8_t* env_mask, void* stream) {
   if (!e) return fail("te_reset: null env");
   DeviceGuard guard(e->device);
+  if (host_io(e) && env_mask) {   // the mask is a host array: staged
+    hipStream_t st = (hipStream_t)stream;
+    TE_H2D(e->hs.mask, env_mask, (size_t)e->p.N);
+    env_mask = e->hs.mask;
+  }
   const int blocks = (e->p.N + 255) / 256;
   launch_by_family(e->family, [&](auto fam) {
     hipLaunchKernelGGL((reset_kernel<decltype(fam)::value>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, e->p, env_mask);
@@ -997,7 +1036,7 @@ __attribute__((visibility("default"))) int te_observe_wingman(te_env* e, int32_t
     return fail("te_observe_wingman: lidar and last_action must be 16-byte aligned");
   DeviceGuard guard(e->device);
   hipStream_t st = (hipStream_t)stream;
-  const size_t n_floats = (size_t)e->p.N * TE_OBS_LIDAR_WORDS;
+  const size_t n_floats = (size_t)e->p.N * lidar_words(e->p.cfg);
   const int nchunks = e->p.Npad / kEPB;
   if (ally_lidar && (n_floats & 3) == 0 && (n_floats >> 2) < (1ull << 32) && e->p.N >= 4096) {  // full-size batches: two launches
     if (!e->ally_scratch) return fail("te_observe_wingman: internal error: no scratch planes (te_create allocates them for caller-driven wingmen)");
@@ -1036,7 +1075,18 @@ __attribute__((visibility("default"))) int te_set_ally_actions(te_env* e, const 
   return te_set_wingman_actions(e, 1, ally_actions, stream);
 }
 
+static int observe_device(te_env* e, float* obs_lidar, float* obs_inertial, float* obs_last_action, void* stream);
 __attribute__((visibility("default"))) int te_observe(te_env* e, float* obs_lidar, float* obs_inertial, float* obs_last_action, void* stream) {
+  if (!host_io(e)) return observe_device(e, obs_lidar, obs_inertial, obs_last_action, stream);
+  DeviceGuard guard(e->device);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t N = (size_t)e->p.N;
+  if (observe_device(e, obs_lidar ? e->hs.lidar : nullptr, obs_inertial ? e->hs.inertial : nullptr, obs_last_action ? e->hs.last_action : nullptr, stream)) return 1;
+  TE_D2H(obs_lidar, e->hs.lidar, N * lidar_words(e->p.cfg) * 4); TE_D2H(obs_inertial, e->hs.inertial, N * 60); TE_D2H(obs_last_action, e->hs.last_action, N * 16);
+  TE_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+static int observe_device(te_env* e, float* obs_lidar, float* obs_inertial, float* obs_last_action, void* stream) {
   if (!e) return fail("te_observe: null env");
   if ((obs_lidar && ((uintptr_t)obs_lidar & 15)) || (obs_last_action && ((uintptr_t)obs_last_action & 15)))
     return fail("te_observe: obs_lidar and obs_last_action must be 16-byte aligned");
@@ -1117,7 +1167,24 @@ __attribute__((visibility("default"))) int te_step(te_env* e, const float* actio
                                                    float* obs_last_action, float* reward, uint8_t* done, int32_t* info,
                                                    float* terminal_lidar, float* terminal_inertial, float* terminal_last_action,
                                                    void* stream) {
-  return step_impl(e, actions, obs_lidar, TE_OBS_LIDAR_WORDS, obs_inertial, obs_last_action, reward, done, info, terminal_lidar,
+  if (host_io(e)) {
+    if (!actions || !reward || !done || !info) return fail("te_step: actions, reward, done and info are required");
+    DeviceGuard guard(e->device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = (size_t)e->p.N, lw = (size_t)lidar_words(e->p.cfg) * 4;
+    const te_env::HostStage& h = e->hs;
+    TE_H2D(h.actions, actions, N * 16);
+    if (step_impl(e, h.actions, obs_lidar ? h.lidar : nullptr, lw / 4, obs_inertial ? h.inertial : nullptr, obs_last_action ? h.last_action : nullptr,
+                  h.reward, h.done, h.info, terminal_lidar ? h.t_lidar : nullptr, terminal_inertial ? h.t_inertial : nullptr,
+                  terminal_last_action ? h.t_last_action : nullptr, nullptr, stream)) return 1;
+    TE_D2H(obs_lidar, h.lidar, N * lw); TE_D2H(obs_inertial, h.inertial, N * 60); TE_D2H(obs_last_action, h.last_action, N * 16);
+    TE_D2H(reward, h.reward, N * 4); TE_D2H(done, h.done, N); TE_D2H(info, h.info, N * 16);
+    // terminal rows are written only for envs that are done: copy whole buffers, the caller reads the rows of its done envs
+    TE_D2H(terminal_lidar, h.t_lidar, N * lw); TE_D2H(terminal_inertial, h.t_inertial, N * 60); TE_D2H(terminal_last_action, h.t_last_action, N * 16);
+    TE_HIP(hipStreamSynchronize(st));
+    return 0;
+  }
+  return step_impl(e, actions, obs_lidar, e ? (size_t)lidar_words(e->p.cfg) : 0, obs_inertial, obs_last_action, reward, done, info, terminal_lidar,
                    terminal_inertial, terminal_last_action, nullptr, stream);
 }
 
@@ -1154,10 +1221,13 @@ __attribute__((visibility("default"))) int te_observe_stacked(te_env* e, float* 
 
 __attribute__((visibility("default"))) int te_random_actions(te_env* e, float* actions, uint64_t seed, uint64_t step_index, void* stream) {
   if (!e || !actions) return fail("te_random_actions: null argument");
-  if ((uintptr_t)actions & 15) return fail("te_random_actions: actions must be 16-byte aligned");
   DeviceGuard guard(e->device);
-  hipLaunchKernelGGL(random_actions_kernel, dim3((e->p.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->p, actions, seed, step_index);
+  hipStream_t st = (hipStream_t)stream;
+  float* dst = host_io(e) ? e->hs.actions : actions;
+  if ((uintptr_t)dst & 15) return fail("te_random_actions: actions must be 16-byte aligned");
+  hipLaunchKernelGGL(random_actions_kernel, dim3((e->p.N + 255) / 256), dim3(256), 0, st, e->p, dst, seed, step_index);
   TE_HIP(hipGetLastError());
+  if (host_io(e)) { TE_D2H(actions, dst, (size_t)e->p.N * 16); TE_HIP(hipStreamSynchronize(st)); }
   return 0;
 }
 
@@ -1175,6 +1245,14 @@ __attribute__((visibility("default"))) int te_get_state(te_env* e, void* dst_dev
   if (te_state_words(e, &need)) return 1;
   if (!dst_device || words != need) return fail("te_get_state: buffer must hold exactly te_state_words() words");
   DeviceGuard guard(e->device);
+  if (host_io(e)) {   // dst is a host buffer
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(planes_to_blob, dim3(1024), dim3(256), 0, st, e->p, e->hs.blob);
+    TE_HIP(hipGetLastError());
+    TE_D2H(dst_device, e->hs.blob, need * 4);
+    TE_HIP(hipStreamSynchronize(st));
+    return 0;
+  }
   hipLaunchKernelGGL(planes_to_blob, dim3(1024), dim3(256), 0, (hipStream_t)stream, e->p, (uint32_t*)dst_device);
   if (e->p.ring)
     TE_HIP(hipMemcpyAsync((uint32_t*)dst_device + (need - ring_words(e)), e->p.ring, ring_words(e) * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1187,6 +1265,11 @@ __attribute__((visibility("default"))) int te_set_state(te_env* e, const void* s
   if (te_state_words(e, &need)) return 1;
   if (!src_device || words != need) return fail("te_set_state: buffer must hold exactly te_state_words() words");
   DeviceGuard guard(e->device);
+  if (host_io(e)) {   // src is a host buffer
+    hipStream_t st = (hipStream_t)stream;
+    TE_H2D(e->hs.blob, src_device, need * 4);
+    src_device = e->hs.blob;
+  }
   hipLaunchKernelGGL(blob_to_planes, dim3(1024), dim3(256), 0, (hipStream_t)stream, e->p, (const uint32_t*)src_device);
   if (e->p.ring)
     TE_HIP(hipMemcpyAsync(e->p.ring, (const uint32_t*)src_device + (need - ring_words(e)), ring_words(e) * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));

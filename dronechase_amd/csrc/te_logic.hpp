@@ -498,6 +498,8 @@ template <int FAMILY, class V> TE_DEV void reset_env(const te_config& c, const V
 // observation (exp03_vFinal_environment.py:200-228)
 // ------------------------------------------------------------------------------------------------
 struct ObsOut { float* lidar; float* inertial; float* last_action; };
+// floats of one own-sphere row: lidar_channels x 13 x 26 (3: distance, flag, time; 2 = the legacy layout without the time plane)
+__host__ __device__ inline int lidar_words(const te_config& c) { return (c.lidar_channels == 2 ? 2 : TE_LIDAR_CHANNELS) * TE_LIDAR_CELLS; }
 struct StepOut { float* reward; uint8_t* done; int32_t* info; ObsOut obs, term; };
 
 // LidarMath.cartesian_to_spherical + normalize + binning (lidar_math.py:24-34,93-96,128-137)
@@ -607,9 +609,9 @@ TE_DEV void write_obs_rows(const ObsOut& o, int env, const float inertial[TE_OBS
 
 // The [nvalid,3,13,26] tile of a block is all ones except <= D-1 cells per env: stream the ones at memset
 // speed (16-byte coalesced stores, no per-element work), barrier, then patch the few hit cells.
-TE_DEV void stream_ones(float* __restrict__ lidar, int env0, int nvalid) {
-  float* base = lidar + (size_t)env0 * TE_OBS_LIDAR_WORDS;  // 64 * 1014 * 4 B per block: 16-byte aligned
-  const int total = nvalid * TE_OBS_LIDAR_WORDS;
+TE_DEV void stream_ones(const te_config& c, float* __restrict__ lidar, int env0, int nvalid) {
+  float* base = lidar + (size_t)env0 * lidar_words(c);  // 64 * 1014 (or 676) * 4 B per block: 16-byte aligned
+  const int total = nvalid * lidar_words(c);
   const int quads = total >> 2;
   const float4 ones = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
   for (int qi = threadIdx.x; qi < quads; qi += blockDim.x) reinterpret_cast<float4*>(base)[qi] = ones;
@@ -624,18 +626,18 @@ TE_DEV void patch_hits(const te_config& c, const uint32_t* sm, const Rows& r, fl
     if (l >= nvalid || !((sm[r.hitmask() * kEPB + l] >> j) & 1u)) continue;
     float* dst = sm[r.done() * kEPB + l] ? t_lidar : lidar;
     if (!dst) continue;
-    dst += (size_t)(env0 + l) * TE_OBS_LIDAR_WORDS + sm[(r.lcell() + j) * kEPB + l];
+    dst += (size_t)(env0 + l) * lidar_words(c) + sm[(r.lcell() + j) * kEPB + l];
     dst[0] = __uint_as_float(sm[(r.lrhat() + j) * kEPB + l]);
     dst[TE_LIDAR_CELLS] = (float)(j < r.P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;  // lidar_math.py:305
-    dst[2 * TE_LIDAR_CELLS] = 0.1f;  // Delta = 1 of a 10-deep ring (perception_snapshot.py:36-37)
+    if (c.lidar_channels != 2) dst[2 * TE_LIDAR_CELLS] = 0.1f;  // Delta = 1 of a 10-deep ring (perception_snapshot.py:36-37)
   }
 }
 // terminal tiles of auto-reset envs (rare): ones, to be patched by patch_hits after the barrier
-TE_DEV void stream_terminal_ones(const uint32_t* sm, const Rows& r, float* __restrict__ t_lidar, int env0, int nvalid) {
+TE_DEV void stream_terminal_ones(const te_config& c, const uint32_t* sm, const Rows& r, float* __restrict__ t_lidar, int env0, int nvalid) {
   for (int l = 0; l < nvalid; ++l) {
     if (!sm[r.done() * kEPB + l]) continue;
-    float* base = t_lidar + (size_t)(env0 + l) * TE_OBS_LIDAR_WORDS;
-    for (int e = threadIdx.x; e < TE_OBS_LIDAR_WORDS; e += blockDim.x) base[e] = 1.0f;
+    float* base = t_lidar + (size_t)(env0 + l) * lidar_words(c);
+    for (int e = threadIdx.x; e < lidar_words(c); e += blockDim.x) base[e] = 1.0f;
   }
 }
 

@@ -9,6 +9,7 @@ from typing import Optional
 
 import numpy as np
 
+from . import config as K
 from . import spaces
 from .vec_env import INFO_KEYS, make_config
 
@@ -29,7 +30,7 @@ class _SingleEnv:
         self._b = BatchedEnv(self.cfg, device)
         self.action_space = spaces.action_space()
         self.stacked = bool(self.cfg.stacked_obs)
-        self.observation_space = spaces.stacked_observation_space() if self.stacked else spaces.observation_space()
+        self.observation_space = spaces.stacked_observation_space() if self.stacked else spaces.observation_space((int(self.cfg.lidar_channels), K.LIDAR_NTHETA, K.LIDAR_NPHI))
 
     def _obs(self, *t):
         if self.stacked:

@@ -142,7 +142,7 @@ class PPO:
             raise ValueError("PPO drives the agent only: an environment with caller-driven wingmen (exp05, evaluation driver mask) "
                              "needs its wingman driver in the loop (ThreatEngageVecEnv.update_model), not this rollout")
         torch.manual_seed(seed)
-        self.policy = (policy or LidarInertialActionPolicy()).to(self.device)
+        self.policy = (policy or LidarInertialActionPolicy(lidar_shape=tuple(env.lidar.shape[1:]))).to(self.device)
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5)
         shapes = {"lidar": tuple(env.lidar.shape[1:]), "inertial_data": (env.inertial.shape[1],), "last_action": (4,)}
         self.buf = RolloutBuffer(self.cfg.n_steps, env.N, shapes, self.device)

@@ -82,7 +82,7 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
         self.backend = backend
         self.num_envs = int(num_envs)
         self.stacked = bool(self.cfg.stacked_obs)  # level5: stacked_spheres + validity_mask instead of lidar
-        self.observation_space = spaces.stacked_observation_space() if self.stacked else spaces.observation_space()
+        self.observation_space = spaces.stacked_observation_space() if self.stacked else spaces.observation_space((int(self.cfg.lidar_channels), K.LIDAR_NTHETA, K.LIDAR_NPHI))
         self.action_space = spaces.action_space()
         self.render_mode = None
         self.reset_infos: List[Dict[str, Any]] = [{} for _ in range(self.num_envs)]

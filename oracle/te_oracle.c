@@ -742,7 +742,16 @@ static void reframe_origin(const real p_other[3], const real p_own[3], const rea
 
 /* FusedLIDAR.update_data own sphere for drone `own` (fused_lidar.py:143-217): every OTHER currently
  * armed drone at its Delta=1 snapshot (= last IMU read), closer wins, flag = type/5, time = 1/10. */
-static void own_sphere(const te_config* c, const ote_drone* dr, int D, int own, float* sphere) {
+/* floats of one own-sphere observation row: lidar_channels x 13 x 26 (3 = FusedLIDAR own sphere; 2 = the legacy LIDAR's layout
+ * without the time plane, sensors/lidar.py:137-145) */
+static int lidar_words(const te_config* c) { return (c->lidar_channels == 2 ? 2 : TE_LIDAR_CHANNELS) * TE_LIDAR_CELLS; }
+static void own_sphere3(const te_config* c, const ote_drone* dr, int D, int own, float* sphere);
+static void own_sphere(const te_config* c, const ote_drone* dr, int D, int own, float* out) {
+  float tmp[TE_OBS_LIDAR_WORDS];
+  own_sphere3(c, dr, D, own, tmp);
+  memcpy(out, tmp, (size_t)lidar_words(c) * sizeof(float));
+}
+static void own_sphere3(const te_config* c, const ote_drone* dr, int D, int own, float* sphere) {
   for (int i = 0; i < TE_OBS_LIDAR_WORDS; ++i) sphere[i] = 1.0f;
   real q[4];
   quat_from_euler(dr[own].obs_euler, q);
@@ -774,7 +783,7 @@ OTE_API void ote_own_sphere_from_poses(int D, int P, const double* pos, const do
     dr[i].armed = armed[i];
   }
   for (int k = 0; k < 3; ++k) dr[own].obs_euler[k] = (real)euler_own[k];
-  own_sphere(&c, dr, D, own, sphere);
+  own_sphere3(&c, dr, D, own, sphere);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1275,7 +1284,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
       for (int i = 0; i < TE_OBS_STACKED_WORDS; ++i) E->out_stacked[(size_t)e * TE_OBS_STACKED_WORDS + i] = 1.0f;
       for (int i = 0; i < TE_STACK_SPHERES; ++i) E->out_mask[(size_t)e * TE_STACK_SPHERES + i] = 0;
     }
-    if (lidar) for (int i = 0; i < TE_OBS_LIDAR_WORDS; ++i) lidar[i] = 1.0f;
+    if (lidar) for (int i = 0; i < lidar_words(c); ++i) lidar[i] = 1.0f;
     if (inertial) inertial_obs(c, &dr[0], 0, max_munition_of(c, 0), inertial);
     if (last_action) for (int k = 0; k < 4; ++k) last_action[k] = 0.0f;
   }
@@ -1437,7 +1446,7 @@ static void stage02_step_env(ote_env* E, int e, const float* action, float* lida
   er->last_dist = cur;
   if (term && c->auto_reset) {
     stage02_reset_env(E, e);
-    if (lidar) for (int i = 0; i < TE_OBS_LIDAR_WORDS; ++i) lidar[i] = 1.0f;
+    if (lidar) for (int i = 0; i < lidar_words(c); ++i) lidar[i] = 1.0f;
     if (inertial) inertial_obs(c, &dr[0], 0, max_munition_of(c, 0), inertial);
     if (last_action) for (int k = 0; k < 4; ++k) last_action[k] = 0.0f;
   }
@@ -1543,7 +1552,7 @@ static void stage01_step_env(ote_env* E, int e, const float* action, float* lida
   er->last_dist = dist3(dr[2].obs_pos, dr[0].obs_pos);
   if (term && c->auto_reset) {
     stage01_reset_env(E, e);
-    if (lidar) for (int i = 0; i < TE_OBS_LIDAR_WORDS; ++i) lidar[i] = 1.0f;
+    if (lidar) for (int i = 0; i < lidar_words(c); ++i) lidar[i] = 1.0f;
     if (inertial) inertial_obs(c, &dr[0], 0, 0, inertial);
     if (last_action) for (int k = 0; k < 4; ++k) last_action[k] = 0.0f;
   }
@@ -1597,9 +1606,9 @@ OTE_API int ote_observe(ote_env* E, float* lidar, float* inertial, float* last_a
     ote_drone* dr = &E->drones[(size_t)e * E->D];
     ote_envrec* er = &E->envs[e];
     if (lidar) {
-      float* L = lidar + (size_t)e * TE_OBS_LIDAR_WORDS;
+      float* L = lidar + (size_t)e * lidar_words(c);
       /* immediately after reset the Delta=1 snapshot does not exist yet: empty sphere */
-      if (er->step == 0) for (int i = 0; i < TE_OBS_LIDAR_WORDS; ++i) L[i] = 1.0f;
+      if (er->step == 0) for (int i = 0; i < lidar_words(c); ++i) L[i] = 1.0f;
       else own_sphere(c, dr, E->D, 0, L);
     }
     if (inertial) inertial_obs(c, &dr[0], er->step, max_munition_of(c, 0), inertial + (size_t)e * TE_OBS_INERTIAL_WORDS);
@@ -1618,8 +1627,8 @@ OTE_API int ote_observe_wingman(ote_env* E, int w, float* lidar, float* inertial
     ote_drone* dr = &E->drones[(size_t)e * E->D];
     ote_envrec* er = &E->envs[e];
     if (lidar) {
-      float* L = lidar + (size_t)e * TE_OBS_LIDAR_WORDS;
-      if (er->step == 0) for (int i = 0; i < TE_OBS_LIDAR_WORDS; ++i) L[i] = 1.0f; /* as ote_observe */
+      float* L = lidar + (size_t)e * lidar_words(c);
+      if (er->step == 0) for (int i = 0; i < lidar_words(c); ++i) L[i] = 1.0f; /* as ote_observe */
       else own_sphere(c, dr, E->D, w, L);
     }
     if (inertial) inertial_obs(c, &dr[w], er->step, max_munition_of(c, w), inertial + (size_t)e * TE_OBS_INERTIAL_WORDS);
@@ -1669,10 +1678,10 @@ OTE_API int ote_step(ote_env* E, const float* actions, float* lidar, float* iner
 #endif
   for (int e = 0; e < N; ++e) {
     const float* a = actions + (size_t)e * 4;
-    float* L = lidar ? lidar + (size_t)e * TE_OBS_LIDAR_WORDS : NULL;
+    float* L = lidar ? lidar + (size_t)e * lidar_words(&E->cfg) : NULL;
     float* In = inertial ? inertial + (size_t)e * TE_OBS_INERTIAL_WORDS : NULL;
     float* La = last_action ? last_action + (size_t)e * 4 : NULL;
-    float* tL = t_lidar ? t_lidar + (size_t)e * TE_OBS_LIDAR_WORDS : NULL;
+    float* tL = t_lidar ? t_lidar + (size_t)e * lidar_words(&E->cfg) : NULL;
     float* tI = t_inertial ? t_inertial + (size_t)e * TE_OBS_INERTIAL_WORDS : NULL;
     float* tA = t_last_action ? t_last_action + (size_t)e * 4 : NULL;
     switch (E->cfg.task) {

@@ -92,7 +92,7 @@ class OracleEnv:
         if not self.h:
             raise RuntimeError("ote_create failed (bad config)")
         N = self.N
-        self.lidar = np.empty((N, K.LIDAR_CHANNELS, K.LIDAR_NTHETA, K.LIDAR_NPHI), np.float32)
+        self.lidar = np.empty((N, int(cfg.lidar_channels), K.LIDAR_NTHETA, K.LIDAR_NPHI), np.float32)
         self.inertial = np.empty((N, K.OBS_INERTIAL_WORDS), np.float32)
         self.last_action = np.empty((N, 4), np.float32)
         self.t_lidar = np.zeros_like(self.lidar)

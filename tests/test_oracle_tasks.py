@@ -334,3 +334,21 @@ def test_stage02_suicide_kill_respawn_and_pursuer_loss():
     env.set_state(b2.w)
     out = step(env)
     assert out["done"] and out["reward"] < -900 and out["info"][2] == 1
+
+
+def test_two_channel_lidar_is_the_three_channel_one_without_the_time_plane():
+    """cfg.lidar_channels = 2 (the legacy LIDAR layout the level2-4 docs quote): same cells, same values, no time plane."""
+    from oracle import te_oracle as O
+    a = O.OracleEnv(O.default_config("exp03", n_envs=64, seed=4), "f32")
+    b = O.OracleEnv(O.default_config("exp03", n_envs=64, seed=4, lidar_channels=2), "f32")
+    a.reset(); b.reset()
+    assert b.lidar.shape == (64, 2, 13, 26)
+    for s in range(25):
+        act = a.random_actions(9, s)
+        la, ia, _, ra, da, _ = a.step(act)
+        lb, ib, _, rb, db, _ = b.step(act)
+        np.testing.assert_array_equal(la[:, :2], lb); np.testing.assert_array_equal(ia, ib)
+        np.testing.assert_array_equal(ra, rb); np.testing.assert_array_equal(da, db)
+        assert (la[:, 2][la[:, 0] < 1] == np.float32(0.1)).all()
+    assert (la[:, 0] < 1).any()
+    np.testing.assert_array_equal(a.t_lidar[:, :2], b.t_lidar)

@@ -166,7 +166,7 @@ def test_training_run_at_16k_envs():
     ppo = PPO(env, PPOConfig(n_steps=32, batch_size=32768, n_epochs=1, use_graph=True), seed=3)
     assert ppo.buf.bytes() > 2 ** 30
     logs = []
-    ppo.collect()                      # captures the graph
+    ppo.collect(); ppo.update()        # captures the graph; MIOpen picks its convolution algorithms for both batch shapes (seconds, once)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ppo.learn(ppo.num_timesteps + 2 * 32 * N, log=logs.append)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
