@@ -245,6 +245,45 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     for (int k = 0; k < 4; ++k) { stv(TE_D_THROTTLE + k, so, 0u); stv(TE_D_SETPOINT + k, so, 0u); }
   }
 
+  // ---- cfg.drone_contact (opt-in; stated model, parity with Bullet unpinned: include/threatengage.h): armed drones as spheres of
+  // contact_radius, resolved once per env.step on the state the sub-step launch left, pairs in slot order, one pass
+  if (c.drone_contact) {
+    float qx[DM], qy[DM], qz[DM], ux[DM], uy[DM], uz[DM];
+    uint32_t moved = 0u;
+#pragma unroll
+    for (int s = 0; s < DM; ++s) {
+      qx[s] = qy[s] = qz[s] = ux[s] = uy[s] = uz[s] = 0.0f;
+      if (s < D) {
+        qx[s] = __uint_as_float(ld(TE_D_POS, s)); qy[s] = __uint_as_float(ld(TE_D_POS + 1, s)); qz[s] = __uint_as_float(ld(TE_D_POS + 2, s));
+        ux[s] = __uint_as_float(ld(TE_D_VEL, s)); uy[s] = __uint_as_float(ld(TE_D_VEL + 1, s)); uz[s] = __uint_as_float(ld(TE_D_VEL + 2, s));
+      }
+    }
+    const float two_r = 2.0f * c.contact_radius;
+#pragma unroll
+    for (int i = 0; i < DM; ++i) {
+#pragma unroll
+      for (int j = i + 1; j < DM; ++j) {
+        float nx = qx[j] - qx[i], ny = qy[j] - qy[i], nz = qz[j] - qz[i];
+        const float d = sqrtf(nx * nx + ny * ny + nz * nz);
+        const bool hit = valid && ((A >> i) & (A >> j) & 1u) != 0u && d < two_r && d > 0.0f;
+        const float inv = hit ? 1.0f / d : 0.0f;
+        nx *= inv; ny *= inv; nz *= inv;
+        const float push = hit ? 0.5f * (two_r - d) : 0.0f;
+        const float vn = (ux[j] - ux[i]) * nx + (uy[j] - uy[i]) * ny + (uz[j] - uz[i]) * nz;
+        const float dv = (hit && vn < 0.0f) ? 0.5f * vn : 0.0f;
+        qx[i] -= push * nx; qy[i] -= push * ny; qz[i] -= push * nz; qx[j] += push * nx; qy[j] += push * ny; qz[j] += push * nz;
+        ux[i] += dv * nx; uy[i] += dv * ny; uz[i] += dv * nz; ux[j] -= dv * nx; uy[j] -= dv * ny; uz[j] -= dv * nz;
+        moved |= hit ? ((1u << i) | (1u << j)) : 0u;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < DM; ++s) {
+      if ((moved >> s) & 1u) {
+        stf(TE_D_POS, s, qx[s]); stf(TE_D_POS + 1, s, qy[s]); stf(TE_D_POS + 2, s, qz[s]);
+        stf(TE_D_VEL, s, ux[s]); stf(TE_D_VEL + 1, s, uy[s]); stf(TE_D_VEL + 2, s, uz[s]);
+      }
+    }
+  }
   const V3 apos{px[0], py[0], pz[0]};
   TE_ESTAMP(3, 0);
   // (the sphere's patches are the kernel's slowest stores — scattered 32-byte sectors, ~2.8 us per hit and env at 65 536 envs,

@@ -856,7 +856,8 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->io_location != TE_IO_DEVICE && cfg->io_location != TE_IO_HOST) return fail("te_create: io_location is TE_IO_DEVICE or TE_IO_HOST");
   if (cfg->io_location == TE_IO_HOST && (cfg->stacked_obs || cfg->ally_policy == TE_ALLY_EXTERNAL || ((uint32_t)cfg->evaluation >> 8) != 0u))
     return fail("te_create: TE_IO_HOST serves te_reset / te_observe / te_step / te_random_actions / te_get_state / te_set_state; the stacked observation and caller-driven wingmen take device pointers");
-  if (cfg->drone_contact != 0) return fail("te_create: drone_contact is not built yet");
+  if (cfg->drone_contact != 0 && cfg->drone_contact != 1) return fail("te_create: drone_contact is 0 or 1");
+  if (cfg->drone_contact && !(cfg->contact_radius > 0.0f)) return fail("te_create: contact_radius must be positive");
   int ndev = 0;
   TE_HIP(hipGetDeviceCount(&ndev));
   if (ndev < 1) return fail("te_create: no HIP device visible; this library has no CPU fallback");
@@ -884,6 +885,8 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     else if (cfg->n_pursuers <= 6 && D <= 18) e->engage_regs = 2;
     if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "lds")) e->engage_regs = 0; }
   }
+  if (cfg->drone_contact && !e->engage_regs)
+    return bail("te_create: cfg.drone_contact is built into engage_kernel: the level4 task family with P <= 6 and P + I <= 18");
   e->p.dense_min = kDenseMin;
   if (const char* v = getenv("TE_DENSE_MIN")) { int n = atoi(v); if (n >= 1 && n <= 65) e->p.dense_min = n; }
   if (cfg->stacked_obs) e->n_fill_waves = 1024;

@@ -1093,6 +1093,36 @@ static void note_state_margin(real m[2], real value, real threshold) {
 }
 
 /* One env.step of the level4 family (exp03_vFinal_environment.py:150-171). */
+/* cfg.drone_contact (OPT-IN, off in every preset; parity with PyBullet unpinned): armed drones collide with each other (collision
+ * group / mask 1 / 1 while armed, 0 / 0 when disarmed: quadcopter.py:484-496).  Stated model, NOT Bullet's solver: spheres of
+ * cfg.contact_radius, resolved ONCE per env.step on the state the sub-step loop leaves (the HIP kernel flies the drones of an env
+ * in different wavefronts, which cannot exchange positions between physics sub-steps), pairs in slot order, one pass: the
+ * overlapping pair is moved apart along the line of centres (half the overlap each) and an approaching normal velocity is
+ * shared out (equal masses, restitution 0: both keep the mean); no friction, no torque.  The IMU reads of this step are not
+ * touched (they were taken before, level4_simulation.py:92-96). */
+static void drone_contacts(const te_config* c, ote_drone* dr, int D, real mg[2]) {
+  const real two_r = (real)2 * (real)c->contact_radius;
+  for (int i = 0; i < D; ++i) {
+    if (!dr[i].armed) continue;
+    for (int j = i + 1; j < D; ++j) {
+      if (!dr[j].armed) continue;
+      real n[3] = {dr[j].pos[0] - dr[i].pos[0], dr[j].pos[1] - dr[i].pos[1], dr[j].pos[2] - dr[i].pos[2]};
+      real d = norm3(n);
+      note_state_margin(mg, d, two_r);
+      if (!(d < two_r) || d <= (real)0) continue;
+      for (int k = 0; k < 3; ++k) n[k] /= d;
+      const real push = (real)0.5 * (two_r - d);
+      real vn = 0;
+      for (int k = 0; k < 3; ++k) vn += (dr[j].vel[k] - dr[i].vel[k]) * n[k];
+      const real dv = vn < 0 ? (real)0.5 * vn : (real)0;
+      for (int k = 0; k < 3; ++k) {
+        dr[i].pos[k] -= push * n[k]; dr[j].pos[k] += push * n[k];
+        dr[i].vel[k] += dv * n[k]; dr[j].vel[k] -= dv * n[k];
+      }
+    }
+  }
+}
+
 static void level4_step_env(ote_env* E, int e, const float* action, float* lidar, float* inertial, float* last_action,
                             float* reward, uint8_t* done, int32_t* info, float* t_lidar, float* t_inertial,
                             float* t_last_action) {
@@ -1181,6 +1211,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
     note_state_margin(mg, n, (real)c->origin_range);
     if (n < (real)c->origin_range) disarm(&dr[j]);
   }
+  if (c->drone_contact) drone_contacts(c, dr, D, mg);
 
   /* compute_reward (:423-515) */
   real score = 0, bonus = 0, penalty = 0;

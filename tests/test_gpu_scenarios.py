@@ -177,3 +177,53 @@ def test_ground_contact_parity():
     with pytest.raises(_lib.TEError, match="level4 task family"):
         BatchedEnv(default_config("stage02", n_envs=64, ground_contact=1), "cuda:0")
     gpu.close(); orc.close()
+
+
+@pytest.mark.parametrize("task", ["exp03", "level5"])
+def test_drone_contact_parity(task):
+    """cfg.drone_contact (opt-in, parity with PyBullet unpinned: tests/test_oracle_contact.py): engage_kernel against the oracle on
+    pursuers that fly into each other: 1 024 envs, pursuers 0 and 1 a few centimetres apart with closing velocities, 5 free-running
+    env-steps compared state by state."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    from dronechase_amd import config as K, default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    from oracle import te_oracle as O
+    from tests.test_gpu_parity import _compare_states
+
+    N = 1024
+    cfg = default_config(task, n_envs=N, motor_noise=1, seed=11, drone_contact=1, auto_reset=0)
+    D = cfg.n_drones
+    orc, gpu = O.OracleEnv(cfg, "f32", threads=8), BatchedEnv(cfg, "cuda:0")
+    orc.reset()
+    b = Blob(orc.get_state(), N, D)
+    rng = np.random.default_rng(1)
+    for e in range(N):
+        c = rng.uniform(-1, 1, 3) + [0, 0, 3]
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        gap = rng.uniform(0.03, 0.25)
+        for s, sign in ((0, -1.0), (1, 1.0)):
+            b.place(e, s, c + sign * 0.5 * gap * d); b.hover_ready(e, s, cfg)
+            b.set_f(e, s, "VEL", -sign * rng.uniform(0.0, 0.8) * d)
+    orc.set_state(b.w); gpu.set_state(torch.from_numpy(b.w.view(np.int32)).cuda())
+    touched = 0
+    step_fn_o = orc.step_stacked if cfg.stacked_obs else orc.step
+    step_fn_g = gpu.step_stacked if cfg.stacked_obs else gpu.step
+    for t in range(5):
+        a = orc.random_actions(3, t)
+        step_fn_o(a); step_fn_g(torch.from_numpy(a).cuda())
+        so, sg = orc.get_state(), gpu.get_state().cpu().numpy().view(np.uint32)
+        n_words = N * (D * K.DRONE_WORDS + K.ENV_WORDS)
+        diff, imis = _compare_states(so[:n_words], sg[:n_words], N, D)
+        ok = orc.state_margins() > 1e-3
+        assert not (imis & ok).any()
+        assert diff[ok & ~imis].max() < (1e-4 if t == 0 else 2e-3), (t, diff[ok & ~imis].max())
+        dr = Blob(sg[:n_words], N, D).dr
+        gapn = np.linalg.norm(dr[:, 0, 0:3].view(np.float32) - dr[:, 1, 0:3].view(np.float32), axis=1)
+        touched += int((np.abs(gapn - 2 * cfg.contact_radius) < 1e-4).sum())
+    assert touched > N // 4       # many pairs sat exactly at the contact distance after a resolution
+    from dronechase_amd import _lib
+    with pytest.raises(_lib.TEError, match="engage_kernel"):
+        BatchedEnv(default_config("stage02", n_envs=64, drone_contact=1), "cuda:0")
+    gpu.close(); orc.close()
