@@ -9,7 +9,7 @@ class Blob:
         self.w = np.array(words, dtype=np.uint32, copy=True)
         self.N, self.D = N, D
         self.dr = self.w[: N * D * K.DRONE_WORDS].reshape(N, D, K.DRONE_WORDS)
-        self.er = self.w[N * D * K.DRONE_WORDS:].reshape(N, K.ENV_WORDS)
+        self.er = self.w[N * D * K.DRONE_WORDS: N * (D * K.DRONE_WORDS + K.ENV_WORDS)].reshape(N, K.ENV_WORDS)  # (level5: the ring follows)
 
     # drone fields -----------------------------------------------------------------------
     def f(self, env, d, name, n=1):
