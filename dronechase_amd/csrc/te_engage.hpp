@@ -554,3 +554,376 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
 }
 
 }  // namespace te
+
+// =================================================================================================================================
+// stage01 / stage02 in the same form (one lane per env, one wave per chunk, the env in registers): BASELINE configs 2 and 3 run a
+// few thousand envs per GPU, where the LDS kernel's phase chain (18 / 42 us at 4 096 / 16 384 envs) is pure latency.
+// =================================================================================================================================
+namespace te {
+
+// buffer-addressed access to the state planes of this lane's env (see engage_kernel)
+struct EnvIO {
+  __amdgpu_buffer_rsrc_t rd, re;
+  int voff; uint32_t plane; uint32_t D;
+  TE_DEV EnvIO(const Params& p, int env)
+      : rd(__builtin_amdgcn_make_buffer_rsrc(p.dstate, 0, (int)((uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)p.D * (uint32_t)p.Npad * 4u), 0x00020000)),
+        re(__builtin_amdgcn_make_buffer_rsrc(p.estate, 0, (int)((uint32_t)TE_ENV_WORDS * (uint32_t)p.Npad * 4u), 0x00020000)),
+        voff(env * 4), plane((uint32_t)p.Npad * 4u), D((uint32_t)p.D) {}
+  TE_DEV uint32_t ld(int w, int s) const { return __builtin_amdgcn_raw_buffer_load_b32(rd, voff, (int)(((uint32_t)w * D + (uint32_t)s) * plane), 0); }
+  TE_DEV float ldf(int w, int s) const { return __uint_as_float(ld(w, s)); }
+  TE_DEV uint32_t le(int w) const { return __builtin_amdgcn_raw_buffer_load_b32(re, voff, (int)((uint32_t)w * plane), 0); }
+  TE_DEV void st(int w, int s, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, rd, voff, (int)(((uint32_t)w * D + (uint32_t)s) * plane), 0); }
+  TE_DEV void stf(int w, int s, float v) const { st(w, s, __float_as_uint(v)); }
+  TE_DEV void stv(int w, int slot, uint32_t v) const {  // per-lane slot
+    __builtin_amdgcn_raw_buffer_store_b32(v, rd, (int)(((uint32_t)slot * (plane >> 2)) * 4u) + voff, (int)((uint32_t)w * D * plane), 0);
+  }
+  TE_DEV void ste(int w, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, re, voff, (int)((uint32_t)w * plane), 0); }
+  TE_DEV void stef(int w, float v) const { ste(w, __float_as_uint(v)); }
+  // Quadcopter.disarm (quadcopter.py:461-478) of a per-lane slot
+  TE_DEV void disarm(int slot) const {
+    stv(TE_D_ARMED, slot, 0u);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { stv(TE_D_VEL + k, slot, 0u); stv(TE_D_OMEGA + k, slot, 0u); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { stv(TE_D_THROTTLE + k, slot, 0u); stv(TE_D_SETPOINT + k, slot, 0u); }
+  }
+  // disarm + replace + IMU + arm of a per-lane slot that ends up armed at `w` (respawn_armed, te_logic.hpp), every word once
+  TE_DEV void respawn(const te_config& c, int slot, V3 w) const {
+    const float w3[3] = {w.x, w.y, w.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      stv(TE_D_POS + k, slot, __float_as_uint(w3[k])); stv(TE_D_FORMATION + k, slot, __float_as_uint(w3[k])); stv(TE_D_OBS_POS + k, slot, __float_as_uint(w3[k]));
+      stv(TE_D_VEL + k, slot, 0u); stv(TE_D_OMEGA + k, slot, 0u); stv(TE_D_OBS_EULER + k, slot, 0u); stv(TE_D_OBS_VEL + k, slot, 0u);
+      stv(TE_D_OBS_RATE + k, slot, 0u); stv(TE_D_QUAT + k, slot, 0u);
+    }
+    stv(TE_D_QUAT + 3, slot, __float_as_uint(1.0f));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { stv(TE_D_THROTTLE + k, slot, 0u); stv(TE_D_SETPOINT + k, slot, 0u); }
+    stv(TE_D_ARMED, slot, 1u); stv(TE_D_MUNITION, slot, (uint32_t)max_munition_of(c, slot)); stv(TE_D_LAST_FIRED, slot, (uint32_t)(-c.cooldown_steps));
+  }
+};
+
+// the agent's own sphere over the drones armed in A (closer wins in slot order), from register positions: owners + cells + ranges
+template <int DM>
+TE_DEV uint32_t own_sphere_regs(const te_config& c, int D, const float (&px)[DM], const float (&py)[DM], const float (&pz)[DM], const float ag[9],
+                                uint32_t A, uint32_t (&cell)[DM], float (&rhat)[DM]) {
+  uint32_t owners = 0u;
+  const V3 apos{px[0], py[0], pz[0]};
+  const Q4 q = quat_of_euler(V3{ag[0], ag[1], ag[2]});
+  const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  const M3 R = rotation(Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2});
+  cell[0] = 0u; rhat[0] = 1.0f;
+#pragma unroll
+  for (int j = 1; j < DM; ++j) {
+    int cj; lidar_cell_fast(c, mul(R, sub(V3{px[j], py[j], pz[j]}, apos)), cj, rhat[j]);
+    cell[j] = (uint32_t)cj;
+    const bool in = j < D && ((A >> j) & 1u) != 0u;
+    uint32_t same = 0u; float r_owner = 2.0f;
+#pragma unroll
+    for (int k = 1; k < j; ++k) {
+      const bool hit = ((owners >> k) & 1u) != 0u && cell[k] == cell[j];
+      same |= (hit ? 1u : 0u) << k;
+      r_owner = hit ? rhat[k] : r_owner;
+    }
+    const bool wins = in && (same ? rhat[j] < r_owner : rhat[j] < 1.0f);
+    owners = wins ? ((owners & ~same) | (1u << j)) : owners;
+  }
+  return owners;
+}
+template <int DM>
+TE_DEV void patch_sphere_regs(const te_config& c, float* __restrict__ dst, int env, int P, uint32_t owners, const uint32_t (&cell)[DM], const float (&rhat)[DM]) {
+  if (!dst) return;
+  dst += (size_t)env * lidar_words(c);
+  const bool time_plane = c.lidar_channels != 2;
+#pragma unroll
+  for (int j = 1; j < DM; ++j) {
+    if ((owners >> j) & 1u) {
+      dst[cell[j]] = rhat[j];
+      dst[TE_LIDAR_CELLS + cell[j]] = (float)(j < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
+      if (time_plane) dst[2 * TE_LIDAR_CELLS + cell[j]] = 0.1f;
+    }
+  }
+}
+// normalize_inertial_data + gun state of the agent (level4/components/utils/normalization.py:6-30,61-110; gun.py:101-113)
+TE_DEV void inertial_row_regs(const te_config& c, float* dst, float x, float y, float z, const float a9[9], int mu, int lfi, int st) {
+  const float two_pi = 2.0f * kPi;
+  dst[0] = clampf(x / c.dome_radius, -1.0f, 1.0f); dst[1] = clampf(y / c.dome_radius, -1.0f, 1.0f); dst[2] = clampf(z / c.dome_radius, -1.0f, 1.0f);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    dst[3 + k] = clampf(a9[3 + k] / c.max_speed, -1.0f, 1.0f);
+    dst[6 + k] = clampf(a9[k] / kPi, -1.0f, 1.0f);
+    dst[9 + k] = clampf(a9[6 + k] / two_pi, -1.0f, 1.0f);
+  }
+  float gs[3];
+  gun_state(c, mu, lfi, st, max_munition_of(c, 0), gs);
+  dst[12] = gs[0]; dst[13] = gs[1]; dst[14] = gs[2];
+}
+// the chunk's [64, 15] rows through LDS: 15 contiguous 256-byte stores; last_action straight from the lane
+TE_DEV void write_rows_regs(const Params& p, const ObsOut& o, float* rows, int lane, bool valid, int env, const float row[TE_OBS_INERTIAL_WORDS], float4 act) {
+  if (o.inertial) {
+#pragma unroll
+    for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) rows[lane * TE_OBS_INERTIAL_WORDS + k] = row[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int n_out = min(64, p.N - (int)blockIdx.x * 64) * TE_OBS_INERTIAL_WORDS;
+    float* dst = o.inertial + (size_t)blockIdx.x * 64 * TE_OBS_INERTIAL_WORDS;
+#pragma unroll
+    for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k)
+      if (k * 64 + lane < n_out) dst[k * 64 + lane] = rows[k * 64 + lane];
+  }
+  if (valid && o.last_action) reinterpret_cast<float4*>(o.last_action)[env] = act;
+}
+TE_DEV void terminal_tiles(const te_config& c, float* t_lidar, bool to_terminal, int lane) {
+  if (!t_lidar) return;
+  for (unsigned long long tb = __ballot(to_terminal); tb; tb &= tb - 1) {
+    const int l = __ffsll((long long)tb) - 1;
+    float* tile = t_lidar + (size_t)(blockIdx.x * 64 + l) * lidar_words(c);
+    for (int e = lane; e < lidar_words(c); e += 64) tile[e] = 1.0f;
+  }
+}
+
+// ---- stage02: L3Stage1.on_step_middle / on_step_end (level3/components/stages.py:144-179,241-344), the restatement of stage02_logic
+template <int PM, int IM>
+__global__ __launch_bounds__(64) void engage_stage02_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+  constexpr int DM = PM + IM;
+  __shared__ float rows[64 * TE_OBS_INERTIAL_WORDS];
+  const te_config& c = p.cfg;
+  const int D = p.D, P = c.n_pursuers;
+  const int lane = threadIdx.x, env = blockIdx.x * 64 + lane;
+  const bool valid = env < p.N;
+  const EnvIO io(p, env);
+  const uint32_t pur_bits = (1u << P) - 1u, all_bits = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u), inv_bits = all_bits & ~pur_bits;
+  float px[DM], py[DM], pz[DM]; uint32_t armed_w[DM];
+  int mun[PM], lf[PM];
+#pragma unroll
+  for (int s = 0; s < DM; ++s) {
+    px[s] = py[s] = pz[s] = 0.0f; armed_w[s] = 0u;
+    if (s < D) { px[s] = io.ldf(TE_D_OBS_POS, s); py[s] = io.ldf(TE_D_OBS_POS + 1, s); pz[s] = io.ldf(TE_D_OBS_POS + 2, s); armed_w[s] = io.ld(TE_D_ARMED, s); }
+  }
+#pragma unroll
+  for (int q = 0; q < PM; ++q) { mun[q] = 0; lf[q] = 0; if (q < P) { mun[q] = (int)io.ld(TE_D_MUNITION, q); lf[q] = (int)io.ld(TE_D_LAST_FIRED, q); } }
+  float ag[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) ag[k] = io.ldf(TE_D_OBS_EULER + k, 0);
+  int step = (int)io.le(TE_E_STEP) + 1;
+  const int max_step = (int)io.le(TE_E_MAX_STEP);
+  int kills = (int)io.le(TE_E_AGENT_KILLS), deads = (int)io.le(TE_E_DEADS);
+  uint32_t episode = io.le(TE_E_EPISODE);
+  const float last = __uint_as_float(io.le(TE_E_PREV_SNAP_MIN));
+  float4 act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (valid) act = reinterpret_cast<const float4*>(actions)[env];
+
+  uint32_t S = 0u, zone = 0u;
+#pragma unroll
+  for (int s = 0; s < DM; ++s) {
+    const uint32_t a = (s < D && armed_w[s] != 0u && valid) ? 1u : 0u;
+    S |= a << s;
+    zone |= (a & (fnorm(V3{px[s], py[s], pz[s]}) > c.dome_radius ? 1u : 0u)) << s;
+  }
+  int tgt[PM]; float dmin[PM];
+#pragma unroll
+  for (int q = 0; q < PM; ++q) {
+    tgt[q] = -1; dmin[q] = 0.0f;
+#pragma unroll
+    for (int j = 1; j < DM; ++j) {
+      const float d = fdist(V3{px[q], py[q], pz[q]}, V3{px[j], py[j], pz[j]});
+      const bool take = q < P && j >= P && ((S >> q) & (S >> j) & 1u) != 0u && (tgt[q] < 0 || d < dmin[q]);
+      tgt[q] = take ? j : tgt[q]; dmin[q] = take ? d : dmin[q];
+    }
+  }
+  // stage02_agent_min_distance: the first armed pursuer's closest invader (0 when there is none), before any respawn
+  float cur = 0.0f;
+  {
+    bool found = false;
+#pragma unroll
+    for (int q = 0; q < PM; ++q) if (!found && q < P && ((S >> q) & 1u)) { found = true; cur = tgt[q] >= 0 ? dmin[q] : 0.0f; }
+  }
+  uint32_t A = S, killed = 0u;
+  if (valid) {
+    io.stef(TE_E_LAST_ACTION + 0, act.x); io.stef(TE_E_LAST_ACTION + 1, act.y); io.stef(TE_E_LAST_ACTION + 2, act.z); io.stef(TE_E_LAST_ACTION + 3, act.w);
+    io.ste(TE_E_STEP, (uint32_t)step); io.ste(TE_E_SNAP_MASK, S);
+  }
+  int shots = 0, exploded = 0;
+#pragma unroll
+  for (int q = 0; q < PM; ++q) {   // shoot_by_ids with the suicide rule (level3/components/quadcopter_manager.py:155-171)
+    if (q < P && valid && ((S >> q) & 1u) && tgt[q] >= 0 && dmin[q] < c.shoot_range) {
+      if (mun[q] == 0) { killed |= 1u << tgt[q]; shots += 1; }
+      else if (gun_available(c, mun[q], lf[q], step)) {
+        mun[q] -= 1; lf[q] = step;
+        io.st(TE_D_MUNITION, q, (uint32_t)mun[q]); io.st(TE_D_LAST_FIRED, q, (uint32_t)step);
+        const U4 r = env_rng(c, env, RNG_HIT, (uint32_t)q, 0, episode, (uint32_t)step);
+        if (u01(r.x) < c.hit_prob) { killed |= 1u << tgt[q]; shots += 1; }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PM; ++q)
+    if (q < P && valid && ((S >> q) & 1u) && tgt[q] >= 0 && dmin[q] < c.explosion_range) { killed |= (1u << q) | (1u << tgt[q]); exploded += 1; }
+  A &= ~killed;
+  for (uint32_t m = killed; m; m &= m - 1) io.disarm(__ffs(m) - 1);
+  kills += shots; deads += exploded;
+  float gs[3];
+  gun_state(c, mun[0], lf[0], step, max_munition_of(c, 0), gs);
+  const bool ready = gs[2] == 1.0f || gs[0] == 0.0f;
+  float bonus = 0.0f, penalty = 0.0f;
+  const float score = ready ? -cur : cur * (2.0f * gs[1] - 1.0f);
+  if (0.01f < last - cur && ready) bonus += c.approach_bonus_gain * fnorm(V3{ag[3], ag[4], ag[5]});
+  bonus += 1000.0f * (float)shots; penalty += 1000.0f * (float)exploded;
+  const bool outside_p = (zone & pur_bits) != 0u, outside_i = (zone & inv_bits) != 0u;
+  if (outside_p) penalty += 1000.0f;
+  const float reward = score + bonus - penalty;
+  const bool term = step > max_step || outside_p || outside_i || __popc(A & pur_bits) < P;
+  const bool to_terminal = valid && term && c.auto_reset;
+  if (valid) {
+    io.ste(TE_E_AGENT_KILLS, (uint32_t)kills); io.ste(TE_E_DEADS, (uint32_t)deads);
+    o.reward[env] = reward; o.done[env] = term ? 1 : 0;
+    reinterpret_cast<int4*>(o.info)[env] = make_int4(kills, 0, deads, 0);
+  }
+  // the observation is taken before the respawn: a drone armed after the step broadcast has no Delta = 1 snapshot yet
+  uint32_t cell[DM]; float rhat[DM];
+  const uint32_t owners = own_sphere_regs<DM>(c, D, px, py, pz, ag, A, cell, rhat);
+  float row[TE_OBS_INERTIAL_WORDS];
+  if (to_terminal) {
+    inertial_row_regs(c, row, px[0], py[0], pz[0], ag, mun[0], lf[0], step);
+    if (o.term.inertial) { for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) o.term.inertial[(size_t)env * TE_OBS_INERTIAL_WORDS + k] = row[k]; }
+    if (o.term.last_action) reinterpret_cast<float4*>(o.term.last_action)[env] = act;
+  }
+  terminal_tiles(c, o.term.lidar, to_terminal, lane);
+  if (valid) patch_sphere_regs<DM>(c, to_terminal ? o.term.lidar : o.obs.lidar, env, P, owners, cell, rhat);
+  // on_step_end: killed invaders come back (stages.py:167-174); last_offsets = current_offsets
+  auto set_pos = [&](int s, V3 w) {
+#pragma unroll
+    for (int k = 0; k < DM; ++k) if (k == s) { px[k] = w.x; py[k] = w.y; pz[k] = w.z; }
+  };
+  if (valid) {
+    for (uint32_t m = inv_bits & ~A; m; m &= m - 1) {
+      const int j = __ffs(m) - 1;
+      const V3 w = stage02_invader_position(c, env, j, episode, (uint32_t)step);
+      io.respawn(c, j, w); set_pos(j, w);
+    }
+    A |= inv_bits;
+    io.stef(TE_E_PREV_SNAP_MIN, cur); io.stef(TE_E_LAST_DIST, cur);
+  }
+  if (to_terminal) {  // L3Stage1.on_reset (stages.py:104-131)
+    episode += 1u; step = 0;
+    io.ste(TE_E_EPISODE, episode); io.ste(TE_E_STEP, 0u); io.ste(TE_E_MAX_STEP, (uint32_t)c.max_step); io.ste(TE_E_ROUND, 0u);
+    io.ste(TE_E_AGENT_KILLS, 0u); io.ste(TE_E_ALLIES_KILLS, 0u); io.ste(TE_E_DEADS, 0u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) io.ste(TE_E_LAST_ACTION + k, 0u);
+    for (int j = P; j < D; ++j) { const V3 w = stage02_invader_position(c, env, j, episode, 0u); io.respawn(c, j, w); set_pos(j, w); }
+    for (int q = 0; q < P; ++q) {
+      const U4 r = env_rng(c, env, RNG_SPAWN_PURSUER, (uint32_t)q, 0, episode, 0);
+      const V3 w = stage02_position(c.pursuer_spawn_radius, 0.0f, u01(r.x), u01(r.y), u01(r.z));
+      io.respawn(c, q, w); set_pos(q, w);
+    }
+#pragma unroll
+    for (int q = 0; q < PM; ++q) if (q < P) { mun[q] = max_munition_of(c, q); lf[q] = -c.cooldown_steps; }
+    A = all_bits;
+    io.ste(TE_E_SNAP_MASK, A);
+    float d0 = 0.0f; bool any = false;   // closest invader of pursuer 0 on the fresh positions
+#pragma unroll
+    for (int j = 1; j < DM; ++j) {
+      const float d = fdist(V3{px[0], py[0], pz[0]}, V3{px[j], py[j], pz[j]});
+      const bool take = j >= P && j < D && (!any || d < d0);
+      d0 = take ? d : d0; any = any || take;
+    }
+    io.stef(TE_E_PREV_SNAP_MIN, d0); io.stef(TE_E_LAST_DIST, d0);
+    act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ag[k] = 0.0f;
+  }
+  inertial_row_regs(c, row, px[0], py[0], pz[0], ag, mun[0], lf[0], step);
+  write_rows_regs(p, o.obs, rows, lane, valid, env, row, act);
+  {  // every armed slot flies as a dense wave outside the level4 family
+    uint32_t dense = 0u;
+    for (int s = 0; s < D; ++s) if (__ballot(valid && ((A >> s) & 1u))) dense |= 1u << s;
+    if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = 0u; }
+  }
+}
+
+// ---- stage01: PyflytL2EnviromentModifiedV2.step after the sim loop (pyflyt_level2_environment_modified_v2.py:137-211), the
+// restatement of stage01_logic.  Slots: 0 = the RL pursuer, 1 = the hovering pursuer, 2 = the position-hold invader.
+__global__ __launch_bounds__(64) void engage_stage01_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+  constexpr int DM = 3;
+  __shared__ float rows[64 * TE_OBS_INERTIAL_WORDS];
+  const te_config& c = p.cfg;
+  const int lane = threadIdx.x, env = blockIdx.x * 64 + lane;
+  const bool valid = env < p.N;
+  const EnvIO io(p, env);
+  const GView g{p.dstate, p.estate, 3, p.Npad, env, 2};
+  float px[DM], py[DM], pz[DM]; uint32_t A = 0u;
+#pragma unroll
+  for (int s = 0; s < DM; ++s) {
+    px[s] = io.ldf(TE_D_OBS_POS, s); py[s] = io.ldf(TE_D_OBS_POS + 1, s); pz[s] = io.ldf(TE_D_OBS_POS + 2, s);
+    A |= (io.ld(TE_D_ARMED, s) != 0u && valid ? 1u : 0u) << s;
+  }
+  int mun0 = (int)io.ld(TE_D_MUNITION, 0), lf0 = (int)io.ld(TE_D_LAST_FIRED, 0);
+  float ag[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) ag[k] = io.ldf(TE_D_OBS_EULER + k, 0);
+  int step = (int)io.le(TE_E_STEP) + 1;
+  const int max_step = (int)io.le(TE_E_MAX_STEP);
+  int kills = (int)io.le(TE_E_AGENT_KILLS);
+  uint32_t episode = io.le(TE_E_EPISODE);
+  const float last = __uint_as_float(io.le(TE_E_LAST_DIST));
+  float4 act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (valid) act = reinterpret_cast<const float4*>(actions)[env];
+  if (valid) {
+    io.stef(TE_E_LAST_ACTION + 0, act.x); io.stef(TE_E_LAST_ACTION + 1, act.y); io.stef(TE_E_LAST_ACTION + 2, act.z); io.stef(TE_E_LAST_ACTION + 3, act.w);
+    io.ste(TE_E_STEP, (uint32_t)step);
+  }
+  const V3 pp{px[0], py[0], pz[0]}, pi{px[2], py[2], pz[2]};
+  const float d = dist(pi, pp);
+  float bonus = 0.0f, penalty = 0.0f;
+  if (d < last) bonus += c.approach_bonus_gain * norm(V3{ag[3], ag[4], ag[5]});
+  const bool caught = d < c.catch_distance;
+  if (caught) bonus += 1000.0f;
+  if (d > c.dome_radius) penalty += 1000.0f;
+  const float reward = -d + bonus - penalty;
+  const bool term = step > max_step || norm(pp) > c.dome_radius || norm(pi) > c.dome_radius;
+  const bool to_terminal = valid && term && c.auto_reset;
+  kills += caught ? 1 : 0;
+  if (valid) {
+    o.reward[env] = reward; o.done[env] = term ? 1 : 0;
+    reinterpret_cast<int4*>(o.info)[env] = make_int4(kills, 0, 0, 0);
+  }
+  uint32_t cell[DM]; float rhat[DM];
+  const uint32_t owners = own_sphere_regs<DM>(c, 3, px, py, pz, ag, A, cell, rhat);
+  float row[TE_OBS_INERTIAL_WORDS];
+  if (to_terminal) {
+    inertial_row_regs(c, row, px[0], py[0], pz[0], ag, mun0, lf0, step);
+    if (o.term.inertial) { for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) o.term.inertial[(size_t)env * TE_OBS_INERTIAL_WORDS + k] = row[k]; }
+    if (o.term.last_action) reinterpret_cast<float4*>(o.term.last_action)[env] = act;
+  }
+  terminal_tiles(c, o.term.lidar, to_terminal, lane);
+  if (valid) patch_sphere_regs<DM>(c, to_terminal ? o.term.lidar : o.obs.lidar, env, 2, owners, cell, rhat);
+  if (valid) {
+    V3 p2 = pi;
+    if (caught) {  // replace_invader_if_close (:147-154): rare, straight through the plane view (it reads the invader's motors and PID memories)
+      p2 = stage01_cube(c, env, RNG_RESPAWN, 2, episode, (uint32_t)step);
+      stage01_replace_invader(c, g, p2, episode, (uint32_t)step);
+      io.ste(TE_E_AGENT_KILLS, (uint32_t)kills);
+      px[2] = p2.x; py[2] = p2.y; pz[2] = p2.z;
+    }
+    io.stef(TE_E_LAST_DIST, dist(p2, pp));  // update_last_distance (:219-223)
+  }
+  if (to_terminal) {  // PyflytL2EnviromentModifiedV2.reset (:83-123): rare, through the plane view as well
+    stage01_reset_env(c, g);
+    episode += 1u; step = 0;
+    const V3 n0 = stage01_cube(c, env, RNG_SPAWN_PURSUER, 0, episode, 0);
+    px[0] = n0.x; py[0] = n0.y; pz[0] = n0.z;
+    mun0 = 0; lf0 = (A & 1u) ? lf0 : -c.cooldown_steps;
+    A = 7u;
+    act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ag[k] = 0.0f;
+  }
+  inertial_row_regs(c, row, px[0], py[0], pz[0], ag, mun0, lf0, step);
+  write_rows_regs(p, o.obs, rows, lane, valid, env, row, act);
+  {
+    uint32_t dense = 0u;
+    for (int s = 0; s < 3; ++s) if (__ballot(valid && ((A >> s) & 1u))) dense |= 1u << s;
+    if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = 0u; }
+  }
+}
+
+}  // namespace te

@@ -762,7 +762,7 @@ struct te_env {
   int family;
   size_t lds_bytes;
   size_t stack_lds_bytes = 0;  // stacked_kernel (level5)
-  int engage_regs = 0;         // level4 family: 1 = engage_kernel<2, 9>, 2 = engage_kernel<6, 12> (te_engage.hpp: the env in registers, one wave per
+  int engage_regs = 0;         // 1 = engage_kernel<2, 9>, 2 = engage_kernel<6, 12> (level4 family), 3 = engage_stage02_kernel<2, 8>, 4 = engage_stage01_kernel (te_engage.hpp: the env in registers, one wave per
                                // chunk); 0 = engage_observe_kernel (LDS phases): other shapes, stage01 / stage02, TE_ENGAGE=lds
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
   uint32_t* ally_scratch = nullptr;  // te_observe_wingman: owner planes between its two launches (te_create allocates them when a wingman is caller-driven)
@@ -883,9 +883,11 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (e->family == FAM_LEVEL4) {
     if (cfg->n_pursuers <= 2 && D <= 11) e->engage_regs = 1;
     else if (cfg->n_pursuers <= 6 && D <= 18) e->engage_regs = 2;
-    if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "lds")) e->engage_regs = 0; }
-  }
-  if (cfg->drone_contact && !e->engage_regs)
+  } else if (e->family == FAM_STAGE02) {
+    if (cfg->n_pursuers <= 2 && D <= 10) e->engage_regs = 3;
+  } else if (e->family == FAM_STAGE01) e->engage_regs = 4;
+  if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "lds")) e->engage_regs = 0; }
+  if (cfg->drone_contact && !(e->engage_regs == 1 || e->engage_regs == 2))
     return bail("te_create: cfg.drone_contact is built into engage_kernel: the level4 task family with P <= 6 and P + I <= 18");
   e->p.dense_min = kDenseMin;
   if (const char* v = getenv("TE_DENSE_MIN")) { int n = atoi(v); if (n >= 1 && n <= 65) e->p.dense_min = n; }
@@ -1153,6 +1155,8 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
             ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}};
   if (e->engage_regs == 1) hipLaunchKernelGGL((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, st, p, actions, o);
   else if (e->engage_regs == 2) hipLaunchKernelGGL((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  else if (e->engage_regs == 3) hipLaunchKernelGGL((engage_stage02_kernel<2, 8>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  else if (e->engage_regs == 4) hipLaunchKernelGGL(engage_stage01_kernel, dim3(b2), dim3(64), 0, st, p, actions, o);
   else launch_by_family(e->family, [&](auto fam) {
     if (e->k2_threads == 512) hipLaunchKernelGGL((engage_observe_kernel<FAM_LEVEL4, 512>), dim3(b2), dim3(512), e->lds_bytes, st, p, actions, o);
     else hipLaunchKernelGGL((engage_observe_kernel<decltype(fam)::value>), dim3(b2), dim3(256), e->lds_bytes, st, p, actions, o);
