@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libthreaten
 EXPORTS = (
     "te_config_default", "te_create", "te_destroy", "te_reset", "te_observe", "te_step", "te_random_actions",
     "te_state_words", "te_get_state", "te_set_state", "te_algorithmic_bytes_per_env_step", "te_profile_begin",
-    "te_profile_end", "te_debug_stamps", "te_abi_version", "te_last_error", "te_step_stacked", "te_observe_stacked", "te_observe_ally", "te_set_ally_actions", "te_wingman_info", "te_calculate_rounds", "te_observe_wingman", "te_set_wingman_actions", "te_quad_preset",
+    "te_profile_end", "te_debug_stamps", "te_abi_version", "te_last_error", "te_step_stacked", "te_observe_stacked", "te_observe_ally", "te_set_ally_actions", "te_wingman_info", "te_calculate_rounds", "te_observe_wingman", "te_set_wingman_actions", "te_quad_preset", "te_step_students",
 )
 
 
@@ -50,6 +50,7 @@ def load() -> C.CDLL:
     L.te_step.argtypes = [vp] + [vp] * 10 + [vp]
     L.te_step_stacked.argtypes = [vp] + [vp] * 12 + [vp]
     L.te_observe_stacked.argtypes = [vp] + [vp] * 4 + [vp]
+    L.te_step_students.argtypes = [vp] + [vp] * 8 + [vp]
     L.te_observe_ally.argtypes = [vp] + [vp] * 4 + [vp]
     L.te_set_ally_actions.argtypes = [vp, vp, vp]
     L.te_wingman_info.argtypes = [vp, vp, vp]

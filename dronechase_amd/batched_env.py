@@ -122,6 +122,20 @@ class BatchedEnv:
                                           self._p(t[0]), self._p(t[1]), self._p(t[2]), self._p(t[3]), self._stream()), "te_step_stacked")
         return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
 
+    def step_students(self):
+        """Level5DumbMultiObs (every wingman scripted): one env.step returning the student observation of EVERY pursuer and the teacher's
+        action for it: (stacked [N,P,6,3,13,26], mask [N,P,6], inertial [N,P,15], last_action [N,P,4], active [N,P], reward, done, info)."""
+        if not hasattr(self, "_students"):
+            N, P, dev = self.N, int(self.cfg.n_pursuers), self.device
+            f32 = dict(dtype=torch.float32, device=dev)
+            self._students = (torch.empty((N, P, K.STACK_SPHERES, K.LIDAR_CHANNELS, K.LIDAR_NTHETA, K.LIDAR_NPHI), **f32),
+                              torch.empty((N, P, K.STACK_SPHERES), dtype=torch.uint8, device=dev), torch.empty((N, P, K.OBS_INERTIAL_WORDS), **f32),
+                              torch.empty((N, P, 4), **f32), torch.empty((N, P), dtype=torch.uint8, device=dev))
+        st = self._students
+        _lib.check(self.L.te_step_students(self._h, self._p(st[0]), self._p(st[1]), self._p(st[2]), self._p(st[3]), self._p(st[4]),
+                                           self._p(self.reward), self._p(self.done), self._p(self.info), self._stream()), "te_step_students")
+        return (*st, self.reward, self.done, self.info)
+
     # caller-driven wingmen (exp05's ally, "nn" drivers of the evaluation task) -----------------
     def observe_wingman(self, wingman: int):
         """Observation of a caller-driven pursuer on the current state (compute_lw_observation, exp05_vFinal_task.py:265-292,

@@ -7,11 +7,12 @@ from __future__ import annotations
 
 import ctypes as C
 
-TE_ABI_VERSION = 4
+TE_ABI_VERSION = 5
 
-TASK_STAGE01, TASK_STAGE02, TASK_EXP02, TASK_EXP03, TASK_EXP04, TASK_LEVEL5, TASK_EXP05, TASK_EVALUATION = 1, 2, 3, 4, 5, 6, 7, 8
+TASK_STAGE01, TASK_STAGE02, TASK_EXP02, TASK_EXP03, TASK_EXP04, TASK_LEVEL5, TASK_EXP05, TASK_EVALUATION, TASK_LEVEL5_DUMB = 1, 2, 3, 4, 5, 6, 7, 8, 9
 TASKS = {"stage01": TASK_STAGE01, "stage02": TASK_STAGE02, "exp02": TASK_EXP02, "exp03": TASK_EXP03,
-         "stage03": TASK_EXP03, "exp04": TASK_EXP04, "level5": TASK_LEVEL5, "exp05": TASK_EXP05, "evaluation": TASK_EVALUATION}
+         "stage03": TASK_EXP03, "exp04": TASK_EXP04, "level5": TASK_LEVEL5, "exp05": TASK_EXP05, "evaluation": TASK_EVALUATION,
+         "level5_dumb": TASK_LEVEL5_DUMB}
 ALLY_NONE, ALLY_BT, ALLY_FROZEN, ALLY_EXTERNAL = 0, 1, 2, 3
 IO_DEVICE, IO_HOST = 0, 1
 QUAD_CF2X_RECALLED, QUAD_CF2X_RECORDED_FIT = 0, 1
@@ -39,9 +40,9 @@ D = dict(POS=0, QUAT=3, VEL=7, OMEGA=10, THROTTLE=13, PID_AV_I=17, PID_AV_E=20, 
          PENDING=48, ALLY_ACTION=48, ARMED=54, MUNITION=55, LAST_FIRED=56, NAV_STATE=57, KILLS=57)
 # word offsets inside an env record (TE_E_*)
 E = dict(STEP=0, MAX_STEP=1, ROUND=2, LAST_DIST=3, AGENT_KILLS=4, ALLIES_KILLS=5, DEADS=6, SNAP_MASK=7, EPISODE=8,
-         LAST_ACTION=9, PREV_SNAP_MIN=13)
+         LAST_ACTION=9, PREV_SNAP_MIN=13, SNAP_MASK_HI=14)
 D_INT_WORDS = (54, 55, 56, 57)
-E_INT_WORDS = (0, 1, 2, 4, 5, 6, 7, 8)
+E_INT_WORDS = (0, 1, 2, 4, 5, 6, 7, 8, 14)
 
 
 class QuadParams(C.Structure):
@@ -77,7 +78,9 @@ class Config(C.Structure):
         ("motor_noise", C.c_int32), ("auto_reset", C.c_int32), ("kamikaze_cone_check", C.c_int32), ("stacked_obs", C.c_int32),
         ("evaluation", C.c_int32), ("ground_contact", C.c_int32), ("ground_z", C.c_float), ("hull_half_height", C.c_float),
         ("control_every_substep", C.c_int32), ("lidar_channels", C.c_int32), ("io_location", C.c_int32),
-        ("drone_contact", C.c_int32), ("contact_radius", C.c_float), ("quad_preset", C.c_int32),
+        ("drone_contact", C.c_int32), ("contact_radius", C.c_float),
+        ("initial_invaders", C.c_int32), ("invaders_per_round", C.c_int32), ("agent_scripted", C.c_int32), ("reward_model", C.c_int32),
+        ("agent_death_terminates", C.c_int32), ("quad_preset", C.c_int32),
         ("quad", QuadParams),
     ]
 

@@ -89,6 +89,7 @@ TE_API int te_config_default(te_config* c, int32_t task) {
   c->control_every_substep = 1; /* level4_simulation.py:92-94: update_control inside the 240 Hz loop */
   c->lidar_channels = TE_LIDAR_CHANNELS; c->io_location = TE_IO_DEVICE;
   c->drone_contact = 0; c->contact_radius = 0.06f; c->quad_preset = TE_QUAD_CF2X_RECALLED;
+  c->initial_invaders = 1; c->invaders_per_round = 1; c->agent_scripted = 0; c->reward_model = TE_REWARD_EXP03; c->agent_death_terminates = 1;
   c->ground_contact = 0; c->ground_z = -6.0f; c->hull_half_height = 0.0125f; /* plane.urdf at z = -6 (entities_manager.py:120-124): opt-in */
   c->n_envs = 1;
   c->seed = 0;
@@ -145,6 +146,18 @@ TE_API int te_config_default(te_config* c, int32_t task) {
       c->ally_policy = TE_ALLY_BT; c->approach_bonus_gain = 1.0f;
       c->stacked_obs = 1;
       break;
+    case TE_TASK_LEVEL5_DUMB: { /* level5_dumb_multiobject_task.py:82-115 */
+      const int initial = 5, per_round = 1, max_invaders = 30;
+      c->n_pursuers = 6 + 1; c->n_invaders = max_invaders;
+      c->initial_invaders = initial; c->invaders_per_round = per_round;
+      c->n_rounds = (int)ceil((double)(max_invaders - initial) / per_round + 1.0);       /* 26 */
+      c->munition = (initial + max_invaders) * c->n_rounds / 2;                          /* 455 */
+      c->dome_radius = 20.0f; c->lidar_radius = 40.0f;
+      c->max_step = 300; c->pursuer_spawn_radius = 2.0f;
+      c->ally_policy = TE_ALLY_BT; c->approach_bonus_gain = 1.0f;
+      c->stacked_obs = 1; c->agent_scripted = 1; c->reward_model = TE_REWARD_L5_DUMB; c->agent_death_terminates = 0;
+      break;
+    }
     case TE_TASK_EVALUATION: /* evaluation_task.py:89-112: one behaviour-tree driver (evaluation_exp01_1bt_app_ready.py:66-68),
                                 TIME_IS_LIMITED False (max_step 0 = no limit), the exp03 constants otherwise */
       c->n_pursuers = 1; c->munition = 20;

@@ -28,6 +28,7 @@
 #pragma once
 #include "te_logic.hpp"
 #include "te_stacked.hpp"
+#include <type_traits>
 
 namespace te {
 
@@ -42,11 +43,11 @@ namespace te {
 #define TE_ESTAMP(idx, wait) do {} while (0)
 #endif
 
-template <class V> TE_DEV void plan_slot_l4(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint32_t& dense, int& n) {
+template <class V> TE_DEV void plan_slot_l4(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint64_t& dense, int& n) {
   const unsigned long long b = __ballot(a);
   const int cnt = __popcll(b);
   if (cnt == 0) return;
-  if (s == 0 || cnt >= dense_min || n + cnt > kMixedCap) { dense |= 1u << s; return; }
+  if (s == 0 || cnt >= dense_min || n + cnt > kMixedCap) { dense |= (uint64_t)1 << s; return; }
   if (a) items[n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | (s << 8));
   n += cnt;
 }
@@ -79,7 +80,7 @@ TE_DEV void lidar_cell_fast(const te_config& c, V3 local, int& cell, float& rhat
 TE_DEV bool spawn_slot_at(const te_config& c, const GView& v, int s, int round, uint32_t episode, bool reset, bool was_armed, V3& where) {
   const int Pn = c.n_pursuers;
   const bool invader = s >= Pn;
-  const bool respawn = invader ? (s - Pn < round && s - Pn < c.n_invaders) : reset;
+  const bool respawn = invader ? (s - Pn < invaders_in_round(c, round)) : reset;
   if (respawn) {
     const U4 r = invader ? env_rng(c, v.env, RNG_SPAWN_INVADER, (uint32_t)s, 0, episode, (uint32_t)round)
                          : env_rng(c, v.env, RNG_SPAWN_PURSUER, (uint32_t)s, 0, episode, 0);
@@ -105,9 +106,100 @@ TE_DEV bool spawn_slot_at(const te_config& c, const GView& v, int s, int round, 
   return respawn;
 }
 
-template <int PM, int IM>
+// buffer-addressed access to the state planes of this lane's env (see engage_kernel)
+struct EnvIO {
+  __amdgpu_buffer_rsrc_t rd, re;
+  int voff; uint32_t plane; uint32_t D;
+  TE_DEV EnvIO(const Params& p, int env)
+      : rd(__builtin_amdgcn_make_buffer_rsrc(p.dstate, 0, (int)((uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)p.D * (uint32_t)p.Npad * 4u), 0x00020000)),
+        re(__builtin_amdgcn_make_buffer_rsrc(p.estate, 0, (int)((uint32_t)TE_ENV_WORDS * (uint32_t)p.Npad * 4u), 0x00020000)),
+        voff(env * 4), plane((uint32_t)p.Npad * 4u), D((uint32_t)p.D) {}
+  TE_DEV uint32_t ld(int w, int s) const { return __builtin_amdgcn_raw_buffer_load_b32(rd, voff, (int)(((uint32_t)w * D + (uint32_t)s) * plane), 0); }
+  TE_DEV float ldf(int w, int s) const { return __uint_as_float(ld(w, s)); }
+  TE_DEV uint32_t le(int w) const { return __builtin_amdgcn_raw_buffer_load_b32(re, voff, (int)((uint32_t)w * plane), 0); }
+  TE_DEV void st(int w, int s, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, rd, voff, (int)(((uint32_t)w * D + (uint32_t)s) * plane), 0); }
+  TE_DEV void stf(int w, int s, float v) const { st(w, s, __float_as_uint(v)); }
+  TE_DEV void stv(int w, int slot, uint32_t v) const {  // per-lane slot
+    __builtin_amdgcn_raw_buffer_store_b32(v, rd, (int)(((uint32_t)slot * (plane >> 2)) * 4u) + voff, (int)((uint32_t)w * D * plane), 0);
+  }
+  TE_DEV void ste(int w, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, re, voff, (int)((uint32_t)w * plane), 0); }
+  TE_DEV void stef(int w, float v) const { ste(w, __float_as_uint(v)); }
+  // Quadcopter.disarm (quadcopter.py:461-478) of a per-lane slot
+  TE_DEV void disarm(int slot) const {
+    stv(TE_D_ARMED, slot, 0u);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { stv(TE_D_VEL + k, slot, 0u); stv(TE_D_OMEGA + k, slot, 0u); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { stv(TE_D_THROTTLE + k, slot, 0u); stv(TE_D_SETPOINT + k, slot, 0u); }
+  }
+  // disarm + replace + IMU + arm of a per-lane slot that ends up armed at `w` (respawn_armed, te_logic.hpp), every word once
+  TE_DEV void respawn(const te_config& c, int slot, V3 w) const {
+    const float w3[3] = {w.x, w.y, w.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      stv(TE_D_POS + k, slot, __float_as_uint(w3[k])); stv(TE_D_FORMATION + k, slot, __float_as_uint(w3[k])); stv(TE_D_OBS_POS + k, slot, __float_as_uint(w3[k]));
+      stv(TE_D_VEL + k, slot, 0u); stv(TE_D_OMEGA + k, slot, 0u); stv(TE_D_OBS_EULER + k, slot, 0u); stv(TE_D_OBS_VEL + k, slot, 0u);
+      stv(TE_D_OBS_RATE + k, slot, 0u); stv(TE_D_QUAT + k, slot, 0u);
+    }
+    stv(TE_D_QUAT + 3, slot, __float_as_uint(1.0f));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { stv(TE_D_THROTTLE + k, slot, 0u); stv(TE_D_SETPOINT + k, slot, 0u); }
+    stv(TE_D_ARMED, slot, 1u); stv(TE_D_MUNITION, slot, (uint32_t)max_munition_of(c, slot)); stv(TE_D_LAST_FIRED, slot, (uint32_t)(-c.cooldown_steps));
+  }
+};
+
+// cfg.drone_contact: armed drones as spheres of contact_radius, resolved once per env.step on the state the sub-step launch left, pairs
+// in slot order, one pass (oracle: drone_contacts).  Compiled into the CONTACT instantiations of engage_kernel only: its 6 * DM
+// registers would otherwise count against every launch (210 -> 363 VGPRs for <2, 9>) although the switch is off in every preset.
+template <int DM>
+TE_DEV void drone_contact_pass(const Params& p, int env, bool valid, uint64_t A) {
+  const te_config& c = p.cfg;
+  const int D = p.D;
+  const EnvIO io(p, env);
+  float qx[DM], qy[DM], qz[DM], ux[DM], uy[DM], uz[DM];
+  uint64_t moved = 0u;
+#pragma unroll
+  for (int s = 0; s < DM; ++s) {
+    qx[s] = qy[s] = qz[s] = ux[s] = uy[s] = uz[s] = 0.0f;
+    if (s < D) {
+      qx[s] = io.ldf(TE_D_POS, s); qy[s] = io.ldf(TE_D_POS + 1, s); qz[s] = io.ldf(TE_D_POS + 2, s);
+      ux[s] = io.ldf(TE_D_VEL, s); uy[s] = io.ldf(TE_D_VEL + 1, s); uz[s] = io.ldf(TE_D_VEL + 2, s);
+    }
+  }
+  const float two_r = 2.0f * c.contact_radius;
+#pragma unroll
+  for (int i = 0; i < DM; ++i) {
+#pragma unroll
+    for (int j = i + 1; j < DM; ++j) {
+      float nx = qx[j] - qx[i], ny = qy[j] - qy[i], nz = qz[j] - qz[i];
+      const float d = sqrtf(nx * nx + ny * ny + nz * nz);
+      const bool hit = valid && ((A >> i) & (A >> j) & 1u) != 0u && d < two_r && d > 0.0f;
+      const float inv = hit ? 1.0f / d : 0.0f;
+      nx *= inv; ny *= inv; nz *= inv;
+      const float push = hit ? 0.5f * (two_r - d) : 0.0f;
+      const float vn = (ux[j] - ux[i]) * nx + (uy[j] - uy[i]) * ny + (uz[j] - uz[i]) * nz;
+      const float dv = (hit && vn < 0.0f) ? 0.5f * vn : 0.0f;
+      qx[i] -= push * nx; qy[i] -= push * ny; qz[i] -= push * nz; qx[j] += push * nx; qy[j] += push * ny; qz[j] += push * nz;
+      ux[i] += dv * nx; uy[i] += dv * ny; uz[i] += dv * nz; ux[j] -= dv * nx; uy[j] -= dv * ny; uz[j] -= dv * nz;
+      moved |= hit ? (((uint64_t)1 << i) | ((uint64_t)1 << j)) : (uint64_t)0;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < DM; ++s) {
+    if ((moved >> s) & 1u) {
+      io.stf(TE_D_POS, s, qx[s]); io.stf(TE_D_POS + 1, s, qy[s]); io.stf(TE_D_POS + 2, s, qz[s]);
+      io.stf(TE_D_VEL, s, ux[s]); io.stf(TE_D_VEL + 1, s, uy[s]); io.stf(TE_D_VEL + 2, s, uz[s]);
+    }
+  }
+}
+
+template <int PM, int IM, bool CONTACT = false>
 __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __restrict__ actions, StepOut o) {
   constexpr int DM = PM + IM;
+  using M = typename std::conditional<(DM > 32), uint64_t, uint32_t>::type;   // slot masks: 64 bits for Level5DumbMultiObs' 37 drones
+  constexpr M one = 1;
+  auto popc = [](M m) { return sizeof(M) == 8 ? __popcll((unsigned long long)m) : __popc((uint32_t)m); };
+  auto lowest = [](M m) { return sizeof(M) == 8 ? __ffsll((long long)m) - 1 : __ffs((int)(uint32_t)m) - 1; };
   __shared__ float xs[DM][4];  // positions of the slots a wave has just respawned, handed back to the env's own lane
   __shared__ float rows[64 * TE_OBS_INERTIAL_WORDS];  // the chunk's [64, 15] inertial rows, transposed here so that they leave as 15 contiguous 256-byte stores
   const te_config& c = p.cfg;
@@ -117,7 +209,8 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   const bool valid = env < p.N;   // planes are padded to Npad (a multiple of 64): lanes beyond N load in bounds and store nothing
   const GView g{p.dstate, p.estate, D, p.Npad, env, P};
   TE_ESTAMP(0, 0);
-  const uint32_t pur_bits = (1u << P) - 1u, all_bits = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u), inv_bits = all_bits & ~pur_bits;
+  const M pur_bits = (one << P) - one, all_bits = D >= (int)(8 * sizeof(M)) ? ~(M)0 : ((one << D) - one), inv_bits = all_bits & ~pur_bits;
+  const bool scripted = all_scripted(c);
 
   // ---- one round of independent loads ----------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dstate, 0, (int)((uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)D * (uint32_t)p.Npad * 4u), 0x00020000);
@@ -169,14 +262,14 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   // ---- masks, closest invader of every pursuer (OffsetHandler over the drones armed NOW, offsets_handler.py:68-95) -------
   // (branch-free on purpose: every pair is evaluated and masked, a few hundred VALU instructions; predicated skips cost more in
   // exec-mask bookkeeping than the arithmetic they save, and the lanes of a wave disagree about which slots are armed anyway)
-  uint32_t S = 0u, zone = 0u, org = 0u;
+  M S = 0, zone = 0, org = 0;
 #pragma unroll
   for (int s = 0; s < DM; ++s) {
-    const uint32_t a = (s < D && armed_w[s] != 0u && valid) ? 1u : 0u;
+    const M a = (s < D && armed_w[s] != 0u && valid) ? one : (M)0;
     const float n = fnorm(V3{px[s], py[s], pz[s]});
     S |= a << s;
-    zone |= (a & (n > c.dome_radius ? 1u : 0u)) << s;
-    org |= (a & (n < c.origin_range ? 1u : 0u)) << s;
+    zone |= (a & (n > c.dome_radius ? one : (M)0)) << s;
+    org |= (a & (n < c.origin_range ? one : (M)0)) << s;
   }
   int tgt[PM]; float dmin[PM];
 #pragma unroll
@@ -185,7 +278,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
 #pragma unroll
     for (int j = 1; j < DM; ++j) {   // identify_closest_invader (offsets_handler.py:256-281): strict '<' in slot order
       const float d = fdist(V3{px[q], py[q], pz[q]}, V3{px[j], py[j], pz[j]});
-      const bool take = q < P && j >= P && ((S >> q) & (S >> j) & 1u) != 0u && (tgt[q] < 0 || d < dmin[q]);
+      const bool take = q < P && j >= P && ((S >> q) & (S >> j) & one) != 0 && (tgt[q] < 0 || d < dmin[q]);
       tgt[q] = take ? j : tgt[q];
       dmin[q] = take ? d : dmin[q];
     }
@@ -198,21 +291,21 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   };
 
   TE_ESTAMP(2, 0);
-  uint32_t A = S;
+  M A = S;
   if (valid) {
     stef(TE_E_LAST_ACTION + 0, act.x); stef(TE_E_LAST_ACTION + 1, act.y); stef(TE_E_LAST_ACTION + 2, act.z); stef(TE_E_LAST_ACTION + 3, act.w);
     ste(TE_E_STEP, (uint32_t)step);
-    ste(TE_E_SNAP_MASK, S);
+    ste(TE_E_SNAP_MASK, (uint32_t)S); ste(TE_E_SNAP_MASK_HI, (uint32_t)((uint64_t)S >> 32));
   }
   // a kill only clears the drone's bit here; Quadcopter.disarm's stores (quadcopter.py:461-478) are issued once per killed
   // drone after the engagement (ONE copy of the 15 stores in the code instead of one per call site), before anything respawns
-  uint32_t killed = 0u;
-  auto kill = [&](int j) { killed |= 1u << j; A &= ~(1u << j); };
+  M killed = 0;
+  auto kill = [&](int j) { killed |= one << j; A &= ~(one << j); };
   int agent_shots = 0, ally_shots = 0, exploded = 0, pursuer_suicided = 0, agent_suicided = 0;
   // process_shoot_range_invaders (exp03_vFinal_task.py:392-413)
 #pragma unroll
   for (int q = 0; q < PM; ++q) {
-    if (q < P && valid && ((S >> q) & 1u) && tgt[q] >= 0 && dmin[q] < c.shoot_range && gun_available(c, mun[q], lf[q], step) && mun[q] > 0) {
+    if (q < P && valid && ((S >> q) & one) && tgt[q] >= 0 && dmin[q] < c.shoot_range && gun_available(c, mun[q], lf[q], step) && mun[q] > 0) {
       mun[q] -= 1; lf[q] = step;
       st(TE_D_MUNITION, q, (uint32_t)mun[q]); st(TE_D_LAST_FIRED, q, (uint32_t)step);
       const U4 r = env_rng(c, env, RNG_HIT, (uint32_t)q, 0, episode, (uint32_t)step);
@@ -226,7 +319,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   // process_explosion_range_invaders (:359-390) on the same (stale) distances
 #pragma unroll
   for (int q = 0; q < PM; ++q) {
-    if (q < P && valid && ((S >> q) & 1u) && tgt[q] >= 0 && dmin[q] < c.explosion_range) {
+    if (q < P && valid && ((S >> q) & one) && tgt[q] >= 0 && dmin[q] < c.explosion_range) {
       kill(q); kill(tgt[q]);
       if (mun[q] == 0 && q == 0) agent_suicided += 1;
       else if (mun[q] == 0) pursuer_suicided += 1;
@@ -236,8 +329,8 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   agent_kills += agent_shots; allies_kills += ally_shots; deads += exploded;
   // process_invaders_in_origin (:656-659); commented out in Evaluation_Task.on_step_middle (evaluation_task.py:397)
   if (!c.evaluation && valid) { killed |= org & inv_bits; A &= ~(org & inv_bits); }
-  for (uint32_t m = killed; m; m &= m - 1) {   // Quadcopter.disarm: static body, velocities / motors / set-point zeroed
-    const int so = ((__ffs(m) - 1) * p.Npad + env) * 4;
+  for (M m = killed; m; m &= m - 1) {   // Quadcopter.disarm: static body, velocities / motors / set-point zeroed
+    const int so = (lowest(m) * p.Npad + env) * 4;
     stv(TE_D_ARMED, so, 0u);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { stv(TE_D_VEL + k, so, 0u); stv(TE_D_OMEGA + k, so, 0u); }
@@ -245,45 +338,8 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     for (int k = 0; k < 4; ++k) { stv(TE_D_THROTTLE + k, so, 0u); stv(TE_D_SETPOINT + k, so, 0u); }
   }
 
-  // ---- cfg.drone_contact (opt-in; stated model, parity with Bullet unpinned: include/threatengage.h): armed drones as spheres of
-  // contact_radius, resolved once per env.step on the state the sub-step launch left, pairs in slot order, one pass
-  if (c.drone_contact) {
-    float qx[DM], qy[DM], qz[DM], ux[DM], uy[DM], uz[DM];
-    uint32_t moved = 0u;
-#pragma unroll
-    for (int s = 0; s < DM; ++s) {
-      qx[s] = qy[s] = qz[s] = ux[s] = uy[s] = uz[s] = 0.0f;
-      if (s < D) {
-        qx[s] = __uint_as_float(ld(TE_D_POS, s)); qy[s] = __uint_as_float(ld(TE_D_POS + 1, s)); qz[s] = __uint_as_float(ld(TE_D_POS + 2, s));
-        ux[s] = __uint_as_float(ld(TE_D_VEL, s)); uy[s] = __uint_as_float(ld(TE_D_VEL + 1, s)); uz[s] = __uint_as_float(ld(TE_D_VEL + 2, s));
-      }
-    }
-    const float two_r = 2.0f * c.contact_radius;
-#pragma unroll
-    for (int i = 0; i < DM; ++i) {
-#pragma unroll
-      for (int j = i + 1; j < DM; ++j) {
-        float nx = qx[j] - qx[i], ny = qy[j] - qy[i], nz = qz[j] - qz[i];
-        const float d = sqrtf(nx * nx + ny * ny + nz * nz);
-        const bool hit = valid && ((A >> i) & (A >> j) & 1u) != 0u && d < two_r && d > 0.0f;
-        const float inv = hit ? 1.0f / d : 0.0f;
-        nx *= inv; ny *= inv; nz *= inv;
-        const float push = hit ? 0.5f * (two_r - d) : 0.0f;
-        const float vn = (ux[j] - ux[i]) * nx + (uy[j] - uy[i]) * ny + (uz[j] - uz[i]) * nz;
-        const float dv = (hit && vn < 0.0f) ? 0.5f * vn : 0.0f;
-        qx[i] -= push * nx; qy[i] -= push * ny; qz[i] -= push * nz; qx[j] += push * nx; qy[j] += push * ny; qz[j] += push * nz;
-        ux[i] += dv * nx; uy[i] += dv * ny; uz[i] += dv * nz; ux[j] -= dv * nx; uy[j] -= dv * ny; uz[j] -= dv * nz;
-        moved |= hit ? ((1u << i) | (1u << j)) : 0u;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < DM; ++s) {
-      if ((moved >> s) & 1u) {
-        stf(TE_D_POS, s, qx[s]); stf(TE_D_POS + 1, s, qy[s]); stf(TE_D_POS + 2, s, qz[s]);
-        stf(TE_D_VEL, s, ux[s]); stf(TE_D_VEL + 1, s, uy[s]); stf(TE_D_VEL + 2, s, uz[s]);
-      }
-    }
-  }
+  // ---- cfg.drone_contact (opt-in; stated model, parity with Bullet unpinned: include/threatengage.h)
+  if (CONTACT) drone_contact_pass<DM>(p, env, valid, (uint64_t)A);
   const V3 apos{px[0], py[0], pz[0]};
   TE_ESTAMP(3, 0);
   // (the sphere's patches are the kernel's slowest stores — scattered 32-byte sectors, ~2.8 us per hit and env at 65 536 envs,
@@ -291,16 +347,16 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   // buffer; the reward is worked out while they drain)
   // increment_max_step (:150-153), compute_termination (:517-569)
   if (agent_shots + ally_shots > 0) max_step += c.step_increment;
-  const int armed_invaders = __popc(A & inv_bits), armed_pursuers = __popc(A & pur_bits);
+  const int armed_invaders = popc(A & inv_bits), armed_pursuers = popc(A & pur_bits);
   const bool all_rounds_over = armed_invaders == 0 && round >= c.n_rounds;
   bool term;
   if (c.evaluation) term = (c.max_step > 0 && step > max_step) || all_rounds_over || zone != 0u || armed_pursuers == 0;
-  else term = step > max_step || all_rounds_over || zone != 0u || armed_pursuers == 0 || !(A & 1u) || apos.z < -5.99f;
+  else term = step > max_step || all_rounds_over || zone != 0u || armed_pursuers == 0 || (c.agent_death_terminates && !(A & one)) || apos.z < -5.99f;
   const bool to_terminal = valid && term && c.auto_reset;
   TE_ESTAMP(4, 0);
   // ---- the agent's own sphere: LidarMath.reframe + binning of every other drone armed NOW, closer wins in slot order
   // (fused_lidar.py:143-217, lidar_math.py:53-83,262-311); empty right after a reset (step 0 never gets here)
-  uint32_t owners = 0u;
+  M owners = 0;
   uint32_t cell[DM]; float rhat[DM];
   {
     const Q4 q = quat_of_euler(V3{ag[0], ag[1], ag[2]});
@@ -310,17 +366,17 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     for (int j = 1; j < DM; ++j) {   // every slot is binned, armed or not (branch-free, as above); only armed ones may own a cell
       int cj; lidar_cell_fast(c, mul(R, sub(V3{px[j], py[j], pz[j]}, apos)), cj, rhat[j]);
       cell[j] = (uint32_t)cj;
-      const bool in = ((A >> j) & 1u) != 0u;
-      uint32_t same = 0u;           // the current owner of the same cell, if any (at most one)
+      const bool in = ((A >> j) & one) != 0;
+      M same = 0;           // the current owner of the same cell, if any (at most one)
       float r_owner = 2.0f;
 #pragma unroll
       for (int k = 1; k < j; ++k) {
-        const bool hit = ((owners >> k) & 1u) != 0u && cell[k] == cell[j];
-        same |= (hit ? 1u : 0u) << k;
+        const bool hit = ((owners >> k) & one) != 0 && cell[k] == cell[j];
+        same |= (hit ? one : (M)0) << k;
         r_owner = hit ? rhat[k] : r_owner;
       }
       const bool wins = in && (same ? rhat[j] < r_owner : rhat[j] < 1.0f);   // an empty cell holds 1.0
-      owners = wins ? ((owners & ~same) | (1u << j)) : owners;
+      owners = wins ? ((owners & ~same) | (one << j)) : owners;
     }
   }
   TE_ESTAMP(5, 0);
@@ -337,7 +393,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     }
     for (int k = 0; k < 3; ++k)
       for (int s = 0; s < P; ++s) p.snap[(size_t)(sr.euler() + k * P + s) * p.Npad + env] = (uint32_t)g.gi(TE_D_OBS_EULER + k, s);
-    p.snap[(size_t)sr.armed() * p.Npad + env] = A;
+    p.snap[(size_t)sr.armed() * p.Npad + env] = (uint32_t)A; p.snap[(size_t)sr.armed_hi() * p.Npad + env] = (uint32_t)((uint64_t)A >> 32);
     p.snap[(size_t)sr.step() * p.Npad + env] = (uint32_t)step;
     p.snap[(size_t)sr.episode() * p.Npad + env] = episode;
     p.snap[(size_t)sr.done() * p.Npad + env] = to_terminal ? 1u : 0u;
@@ -378,7 +434,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
       const bool time_plane = c.lidar_channels != 2;
 #pragma unroll
       for (int j = 1; j < DM; ++j) {
-        if ((owners >> j) & 1u) {
+        if ((owners >> j) & one) {
           dst[cell[j]] = rhat[j];
           dst[TE_LIDAR_CELLS + cell[j]] = (float)(j < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
           if (time_plane) dst[2 * TE_LIDAR_CELLS + cell[j]] = 0.1f;
@@ -394,11 +450,11 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     gun_state(c, mun[0], lf[0], step, max_munition_of(c, 0), gs);
     const float dist_origin = fnorm(apos);
     int ally = -1;  // identify_closest_ally (offsets_handler.py:167-190)
-    if ((S & 1u) && __popc(S & pur_bits) > 1) {
+    if ((S & one) && popc(S & pur_bits) > 1) {
       float bd = 0.0f;
 #pragma unroll
       for (int a = 1; a < PM; ++a) {
-        if (a < P && ((S >> a) & 1u)) {
+        if (a < P && ((S >> a) & one)) {
           const float d = fdist(V3{px[a], py[a], pz[a]}, apos);
           if (ally < 0 || d < bd) { ally = a; bd = d; }
         }
@@ -406,11 +462,28 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     }
     int target = -1;
 #pragma unroll
-    for (int q = 0; q < PM; ++q) if (q == (ally < 0 ? 0 : ally) && ((S >> q) & 1u)) target = tgt[q];
+    for (int q = 0; q < PM; ++q) if (q == (ally < 0 ? 0 : ally) && ((S >> q) & one)) target = tgt[q];
     const V3 tp = target >= 0 ? pos_of(target) : V3{0.0f, 0.0f, 0.0f};
     cur_dist = fdist(apos, tp);
     const bool ready = gs[2] == 1.0f || gs[0] == 0.0f;
     float bonus = 0.0f, penalty = 0.0f;
+    if (c.reward_model == TE_REWARD_L5_DUMB) {  // Level5DumbMultiObjectTask.compute_reward (level5_dumb_multiobject_task.py:452-553)
+      const float SAFE = 5.0f;
+      float score = -cur_dist;
+      if (!ready) {                               // keep away while reloading: distance counts for, closeness against
+        score = cur_dist;
+        if (cur_dist < SAFE) penalty += (SAFE - cur_dist) / SAFE * 500.0f;
+      }
+      if (gs[2] == 0.0f && gs[0] > 0.0f && (cur_dist - last_dist) > 0.01f) bonus += 100.0f;
+      if (agent_shots > 0) bonus += (float)agent_shots * 1000.0f;
+      if (ally_shots > 0 || pursuer_suicided > 0) bonus += 0.5f * (float)(ally_shots + pursuer_suicided) * 1000.0f;
+      if (agent_suicided > 0) penalty += 2.0f * (float)agent_suicided * 1000.0f;
+      if (exploded > 0) penalty += 1000.0f * (float)exploded;
+      if (apos.z < -5.0f) penalty += fminf(-5.0f - apos.z, 1.0f) * 1000.0f;
+      if (zone & pur_bits) penalty += 1000.0f;
+      if (dist_origin > c.born_radius - 2.0f) penalty += fminf(dist_origin - (c.born_radius - 2.0f), 1000.0f);
+      reward = clampf(score + bonus - penalty, -3000.0f, 3000.0f);
+    } else {
     if (0.01f < last_dist - cur_dist && ready) bonus += c.approach_bonus_gain * fnorm(V3{ag[3], ag[4], ag[5]});
     const float score = ready ? -cur_dist : cur_dist * (2.0f * gs[1] - 1.0f);
     if (agent_shots > 0 || agent_suicided > 0) bonus += (float)(agent_shots + agent_suicided) * 1000.0f;
@@ -420,6 +493,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     if (zone & pur_bits) penalty += 1000.0f;
     if (dist_origin > c.born_radius - 2.0f) penalty += dist_origin - c.born_radius - 2.0f;  // literal
     reward = score + bonus - penalty;
+    }
   }
   if (valid) {
     if (!c.evaluation) stef(TE_E_LAST_DIST, cur_dist);
@@ -433,16 +507,16 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   TE_ESTAMP(6, 0);
   // ---- on_step_end (:321-333): next wave when this one is cleared and a pursuer is alive; SB3 auto-reset -------------------
   uint32_t task = 0u;   // round | reset << 8: the slots of this env have to be respawned
-  uint32_t snap_mask = S;
+  M snap_mask = S;
   auto mask_after_spawn = [&](int rnd, bool reset) {
-    uint32_t m = reset ? pur_bits : (A & pur_bits);
-    const int n = rnd < c.n_invaders ? rnd : c.n_invaders;
-    return m | ((((1u << n) - 1u) << P) & all_bits);
+    const M m = reset ? pur_bits : (A & pur_bits);
+    const int n = invaders_in_round(c, rnd);
+    return (M)(m | ((((one << n) - one) << P) & all_bits));
   };
   if (valid && !term && armed_invaders == 0 && armed_pursuers > 0) {
     round = round + (round < c.n_rounds ? 1 : c.n_rounds);  // advance_round (:155-175)
     snap_mask = mask_after_spawn(round, false);
-    ste(TE_E_ROUND, (uint32_t)round); ste(TE_E_SNAP_MASK, snap_mask);
+    ste(TE_E_ROUND, (uint32_t)round); ste(TE_E_SNAP_MASK, (uint32_t)snap_mask); ste(TE_E_SNAP_MASK_HI, (uint32_t)((uint64_t)snap_mask >> 32));
     task = (uint32_t)round;
   }
   if (to_terminal) {  // Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146): the env record here, the slots below
@@ -453,26 +527,27 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     stef(TE_E_LAST_DIST, c.dome_radius);
 #pragma unroll
     for (int k = 0; k < 4; ++k) ste(TE_E_LAST_ACTION + k, 0u);
-    ste(TE_E_SNAP_MASK, snap_mask);
+    ste(TE_E_SNAP_MASK, (uint32_t)snap_mask); ste(TE_E_SNAP_MASK_HI, (uint32_t)((uint64_t)snap_mask >> 32));
     act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
     for (int k = 0; k < 9; ++k) ag[k] = 0.0f;
     task = 1u | (1u << 8);
   }
   // ---- spawn: the D slots of a respawning env are taken by the lanes of the wave (lane k = slot k), env by env -------------
-  uint32_t armed_post = A;
+  M armed_post = A;
   {
     unsigned long long sb = __ballot(task != 0u);
     for (; sb; sb &= sb - 1) {
       const int l = __ffsll((long long)sb) - 1;
       const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)task, l);
       const uint32_t ep = (uint32_t)__builtin_amdgcn_readlane((int)episode, l);
-      const uint32_t armed_l = (uint32_t)__builtin_amdgcn_readlane((int)A, l);   // the env's flags after the engagement
+      const M armed_l = (M)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)A, l) |
+                            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)A >> 32), l) << 32));   // the env's flags after the engagement
       const bool reset = (t >> 8) != 0u;
       if (lane < D) {
         const GView gv{p.dstate, p.estate, D, p.Npad, (int)(blockIdx.x * 64 + l), P};
         V3 w{0.0f, 0.0f, 0.0f};
-        const bool placed = spawn_slot_at(c, gv, lane, (int)(t & 0xFFu), ep, reset, ((armed_l >> lane) & 1u) != 0u, w);
+        const bool placed = spawn_slot_at(c, gv, lane, (int)(t & 0xFFu), ep, reset, ((armed_l >> lane) & one) != 0, w);
         xs[lane][0] = w.x; xs[lane][1] = w.y; xs[lane][2] = w.z; xs[lane][3] = placed ? 1.0f : 0.0f;
       }
       // single-wave workgroup: the LDS operations of one wave execute in order; only the compiler and the LDS counter have to be
@@ -509,22 +584,22 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   // commands of the next step (Task.on_step_start -> LoyalWingmanBehaviorTree.update, loyalwingman_navigator.py:238-352)
   if (valid) {
     int first_skipped = -1;  // drive_loyalwingmen: get_armed_pursuers()[1:] — with the agent dead the first armed ally is skipped
-    if (!c.evaluation && !(armed_post & 1u)) first_skipped = (armed_post & pur_bits & ~1u) ? __ffs(armed_post & pur_bits & ~1u) - 1 : -1;
+    if (!scripted && !(armed_post & one)) first_skipped = (armed_post & pur_bits & ~one) ? lowest(armed_post & pur_bits & ~one) : -1;
 #pragma unroll
     for (int q = 0; q < PM; ++q) {
       if (q < P) {
         stf(TE_X_REF + 0, q, px[q]); stf(TE_X_REF + 1, q, py[q]); stf(TE_X_REF + 2, q, pz[q]);
-        if ((q > 0 || c.evaluation) && ((armed_post >> q) & 1u) && q != first_skipped) {
+        if ((q > 0 || scripted) && ((armed_post >> q) & one) && q != first_skipped) {
           float out[3] = {0.0f, 0.0f, 0.0f};
           const bool ext = driven_externally(c, q);
           if (!ext && c.ally_policy == TE_ALLY_BT) {
             const V3 me{px[q], py[q], pz[q]};
             if (gun_available(c, mun[q], lf[q], step)) {
               int t = -1; float bd = 0.0f; V3 tp{0.0f, 0.0f, 0.0f};
-              if ((snap_mask >> q) & 1u) {
+              if ((snap_mask >> q) & one) {
 #pragma unroll
                 for (int j = 1; j < DM; ++j) {
-                  if (j >= P && ((snap_mask >> j) & 1u)) {
+                  if (j >= P && ((snap_mask >> j) & one)) {
                     const V3 pj{px[j], py[j], pz[j]};
                     const float d = fdist(me, pj);
                     if (t < 0 || d < bd) { t = j; bd = d; tp = pj; }
@@ -544,9 +619,9 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   TE_ESTAMP(9, 0);
   // ---- what the next sub-step launch has to fly for this chunk (post-spawn flags)
   {
-    uint32_t dense = 0u; int n = 0;
+    uint64_t dense = 0u; int n = 0;
     uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
-    for (int s = 0; s < D; ++s) plan_slot_l4<void>(items, p.dense_min, lane, s, valid && ((armed_post >> s) & 1u), dense, n);
+    for (int s = 0; s < D; ++s) plan_slot_l4<void>(items, p.dense_min, lane, s, valid && ((armed_post >> s) & one) != 0, dense, n);
     if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = (uint32_t)n; }
   }
   TE_ESTAMP(10, 0);
@@ -560,48 +635,6 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
 // few thousand envs per GPU, where the LDS kernel's phase chain (18 / 42 us at 4 096 / 16 384 envs) is pure latency.
 // =================================================================================================================================
 namespace te {
-
-// buffer-addressed access to the state planes of this lane's env (see engage_kernel)
-struct EnvIO {
-  __amdgpu_buffer_rsrc_t rd, re;
-  int voff; uint32_t plane; uint32_t D;
-  TE_DEV EnvIO(const Params& p, int env)
-      : rd(__builtin_amdgcn_make_buffer_rsrc(p.dstate, 0, (int)((uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)p.D * (uint32_t)p.Npad * 4u), 0x00020000)),
-        re(__builtin_amdgcn_make_buffer_rsrc(p.estate, 0, (int)((uint32_t)TE_ENV_WORDS * (uint32_t)p.Npad * 4u), 0x00020000)),
-        voff(env * 4), plane((uint32_t)p.Npad * 4u), D((uint32_t)p.D) {}
-  TE_DEV uint32_t ld(int w, int s) const { return __builtin_amdgcn_raw_buffer_load_b32(rd, voff, (int)(((uint32_t)w * D + (uint32_t)s) * plane), 0); }
-  TE_DEV float ldf(int w, int s) const { return __uint_as_float(ld(w, s)); }
-  TE_DEV uint32_t le(int w) const { return __builtin_amdgcn_raw_buffer_load_b32(re, voff, (int)((uint32_t)w * plane), 0); }
-  TE_DEV void st(int w, int s, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, rd, voff, (int)(((uint32_t)w * D + (uint32_t)s) * plane), 0); }
-  TE_DEV void stf(int w, int s, float v) const { st(w, s, __float_as_uint(v)); }
-  TE_DEV void stv(int w, int slot, uint32_t v) const {  // per-lane slot
-    __builtin_amdgcn_raw_buffer_store_b32(v, rd, (int)(((uint32_t)slot * (plane >> 2)) * 4u) + voff, (int)((uint32_t)w * D * plane), 0);
-  }
-  TE_DEV void ste(int w, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, re, voff, (int)((uint32_t)w * plane), 0); }
-  TE_DEV void stef(int w, float v) const { ste(w, __float_as_uint(v)); }
-  // Quadcopter.disarm (quadcopter.py:461-478) of a per-lane slot
-  TE_DEV void disarm(int slot) const {
-    stv(TE_D_ARMED, slot, 0u);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { stv(TE_D_VEL + k, slot, 0u); stv(TE_D_OMEGA + k, slot, 0u); }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { stv(TE_D_THROTTLE + k, slot, 0u); stv(TE_D_SETPOINT + k, slot, 0u); }
-  }
-  // disarm + replace + IMU + arm of a per-lane slot that ends up armed at `w` (respawn_armed, te_logic.hpp), every word once
-  TE_DEV void respawn(const te_config& c, int slot, V3 w) const {
-    const float w3[3] = {w.x, w.y, w.z};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      stv(TE_D_POS + k, slot, __float_as_uint(w3[k])); stv(TE_D_FORMATION + k, slot, __float_as_uint(w3[k])); stv(TE_D_OBS_POS + k, slot, __float_as_uint(w3[k]));
-      stv(TE_D_VEL + k, slot, 0u); stv(TE_D_OMEGA + k, slot, 0u); stv(TE_D_OBS_EULER + k, slot, 0u); stv(TE_D_OBS_VEL + k, slot, 0u);
-      stv(TE_D_OBS_RATE + k, slot, 0u); stv(TE_D_QUAT + k, slot, 0u);
-    }
-    stv(TE_D_QUAT + 3, slot, __float_as_uint(1.0f));
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { stv(TE_D_THROTTLE + k, slot, 0u); stv(TE_D_SETPOINT + k, slot, 0u); }
-    stv(TE_D_ARMED, slot, 1u); stv(TE_D_MUNITION, slot, (uint32_t)max_munition_of(c, slot)); stv(TE_D_LAST_FIRED, slot, (uint32_t)(-c.cooldown_steps));
-  }
-};
 
 // the agent's own sphere over the drones armed in A (closer wins in slot order), from register positions: owners + cells + ranges
 template <int DM>
@@ -834,8 +867,8 @@ __global__ __launch_bounds__(64) void engage_stage02_kernel(Params p, const floa
   inertial_row_regs(c, row, px[0], py[0], pz[0], ag, mun[0], lf[0], step);
   write_rows_regs(p, o.obs, rows, lane, valid, env, row, act);
   {  // every armed slot flies as a dense wave outside the level4 family
-    uint32_t dense = 0u;
-    for (int s = 0; s < D; ++s) if (__ballot(valid && ((A >> s) & 1u))) dense |= 1u << s;
+    uint64_t dense = 0u;
+    for (int s = 0; s < D; ++s) if (__ballot(valid && ((A >> s) & 1u))) dense |= (uint64_t)1 << s;
     if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = 0u; }
   }
 }
@@ -920,8 +953,8 @@ __global__ __launch_bounds__(64) void engage_stage01_kernel(Params p, const floa
   inertial_row_regs(c, row, px[0], py[0], pz[0], ag, mun0, lf0, step);
   write_rows_regs(p, o.obs, rows, lane, valid, env, row, act);
   {
-    uint32_t dense = 0u;
-    for (int s = 0; s < 3; ++s) if (__ballot(valid && ((A >> s) & 1u))) dense |= 1u << s;
+    uint64_t dense = 0u;
+    for (int s = 0; s < 3; ++s) if (__ballot(valid && ((A >> s) & 1u))) dense |= (uint64_t)1 << s;
     if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = 0u; }
   }
 }

@@ -94,7 +94,7 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
   V3 pf{0, 0, 0}, pt{0, 0, 0};
   uint32_t episode = 0, step_index = 0;
   if (active) {
-    const bool scripted0 = FAMILY == FAM_LEVEL4 && c.evaluation != 0;  // Evaluation_Task: pursuer 0 obeys the behaviour tree too
+    const bool scripted0 = FAMILY == FAM_LEVEL4 && all_scripted(c);  // Evaluation_Task / Level5DumbMultiObjectTask: pursuer 0 obeys the behaviour tree too
     if (slot == 0 && !scripted0) act = reinterpret_cast<const float4*>(actions)[env];
     else if (FAMILY == FAM_LEVEL4) {
       if (slot < c.n_pursuers) {  // ally: command prepared by the previous engage/observe launch (or reset)
@@ -125,7 +125,7 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
 
   // ---- set-point for this env.step
   float sp[4];
-  if (slot == 0 && !(FAMILY == FAM_LEVEL4 && c.evaluation != 0)) {  // RL agent: Quadcopter.drive (quadcopter.py:398-413)
+  if (slot == 0 && !(FAMILY == FAM_LEVEL4 && all_scripted(c))) {  // RL agent: Quadcopter.drive (quadcopter.py:398-413)
     command_to_velocity(act.x, act.y, act.z, act.w, sp[0], sp[1], sp[3]);
     sp[2] = 0.0f;
   } else {
@@ -275,8 +275,9 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   if (slot >= D) return;
   // Does this (slot, chunk) fly as a dense wave?  One wave-uniform SCALAR load: the ~8 000 idle waves of a launch used
   // to wait for a vector flag load (and issue a background store) behind the fill waves' stores: +15 us per launch.
-  const uint32_t chunk_mask = __builtin_amdgcn_readfirstlane(((const uint32_t* __restrict__)p.slot_mask)[chunk]);
-  if (!((chunk_mask >> slot) & 1u)) return;
+  const uint32_t* __restrict__ sm32 = reinterpret_cast<const uint32_t*>(p.slot_mask);
+  const uint32_t chunk_mask = __builtin_amdgcn_readfirstlane(sm32[2 * chunk + (slot >> 5)]);   // the 32-bit half that holds this slot's bit
+  if (!((chunk_mask >> (slot & 31)) & 1u)) return;
   const int env = chunk * 64 + lane;  // planes are padded to Npad: lanes beyond N still read in bounds
   fly<FAMILY, NOISE, false, CES>(p, actions, slot, env, env < p.N);
 }
@@ -308,21 +309,24 @@ __global__ __launch_bounds__(256) void snapshot_kernel(Params p) {
   p.snap[(size_t)sr.step() * p.Npad + env] = (uint32_t)v.egi(TE_E_STEP);
   p.snap[(size_t)sr.episode() * p.Npad + env] = (uint32_t)v.egi(TE_E_EPISODE);
   p.snap[(size_t)sr.done() * p.Npad + env] = 0u;
+  uint32_t hi = 0u;
+  for (int s = 32; s < p.D; ++s) hi |= (v.gi(TE_D_ARMED, s) ? 1u : 0u) << (s - 32);
+  p.snap[(size_t)sr.armed_hi() * p.Npad + env] = hi;
 }
 // The flight plan of a chunk for the next sub-step launch, by ONE wave whose lanes are the chunk's 64 envs, slot by slot:
 // slots armed in >= kDenseMin envs (and the agent's) fly as dense waves (bit in slot_mask), the armed (env, slot) pairs of
 // the other slots go to the mixed list in slot order.  `a` = this lane's env has drone s armed (false for lanes >= nvalid).
 template <int FAMILY>
-TE_DEV void plan_slot(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint32_t& dense, int& n) {
+TE_DEV void plan_slot(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint64_t& dense, int& n) {
   const unsigned long long b = __ballot(a);
   const int cnt = __popcll(b);
   if (cnt == 0) return;
-  if (FAMILY != FAM_LEVEL4 || s == 0 || cnt >= dense_min || n + cnt > kMixedCap) { dense |= 1u << s; return; }
+  if (FAMILY != FAM_LEVEL4 || s == 0 || cnt >= dense_min || n + cnt > kMixedCap) { dense |= (uint64_t)1 << s; return; }
   // rank of this lane among the armed ones: v_mbcnt counts the set bits of b below the lane
   if (a) items[n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | (s << 8));
   n += cnt;
 }
-TE_DEV void plan_done(const Params& p, int chunk, int lane, uint32_t dense, int n) {
+TE_DEV void plan_done(const Params& p, int chunk, int lane, uint64_t dense, int n) {
   if (lane == 0) { p.slot_mask[chunk] = dense; p.mixed_count[chunk] = (uint32_t)n; }
 }
 // rebuild slot_mask from the armed planes (after te_create / te_reset / te_set_state; during a rollout the
@@ -330,7 +334,7 @@ TE_DEV void plan_done(const Params& p, int chunk, int lane, uint32_t dense, int 
 template <int FAMILY>
 __global__ __launch_bounds__(64) void census_kernel(Params p) {
   const int chunk = blockIdx.x, l = threadIdx.x, env = chunk * 64 + l;
-  uint32_t dense = 0u; int n = 0;
+  uint64_t dense = 0u; int n = 0;
   uint16_t* items = p.mixed_items + (size_t)chunk * kMixedCap;
   for (int s = 0; s < p.D; ++s) plan_slot<FAMILY>(items, p.dense_min, l, s, env < p.N && p.dstate[((size_t)TE_D_ARMED * p.D + s) * p.Npad + env] != 0u, dense, n);
   plan_done(p, chunk, l, dense, n);
@@ -436,7 +440,8 @@ __global__ __launch_bounds__(THREADS) void engage_observe_kernel(Params p, const
       else if (w == sr.armed()) v = sm[r.anow() * kEPB + l];
       else if (w == sr.step()) v = sm[r.sstep() * kEPB + l];
       else if (w == sr.episode()) v = sm[r.sepis() * kEPB + l];
-      else v = sm[r.done() * kEPB + l];
+      else if (w == sr.done()) v = sm[r.done() * kEPB + l];
+      else v = 0u;   // armed_hi: this kernel serves at most 32 drones per env
       p.snap[(size_t)w * p.Npad + env0 + l] = v;
     }
     __syncthreads();  // the spawn phase overwrites the obs_pos rows
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(THREADS) void engage_observe_kernel(Params p, const
     emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, blockDim.x);
   }
   if (threadIdx.x < kEPB) {  // what the next sub-step launch has to fly for this chunk (post-spawn flags)
-    uint32_t dense = 0u; int n = 0;
+    uint64_t dense = 0u; int n = 0;
     uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
     for (int s = 0; s < p.D; ++s)
       plan_slot<FAMILY>(items, p.dense_min, (int)threadIdx.x, s, (int)threadIdx.x < nvalid && sm[(r.armed() + s) * kEPB + threadIdx.x] != 0u, dense, n);
@@ -765,6 +770,7 @@ struct te_env {
   int engage_regs = 0;         // 1 = engage_kernel<2, 9>, 2 = engage_kernel<6, 12> (level4 family), 3 = engage_stage02_kernel<2, 8>, 4 = engage_stage01_kernel (te_engage.hpp: the env in registers, one wave per
                                // chunk); 0 = engage_observe_kernel (LDS phases): other shapes, stage01 / stage02, TE_ENGAGE=lds
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
+  float* zero_actions = nullptr;     // te_step_students: the [N,4] action batch nobody reads (every pursuer is scripted)
   uint32_t* ally_scratch = nullptr;  // te_observe_wingman: owner planes between its two launches (te_create allocates them when a wingman is caller-driven)
   // cfg.io_location == TE_IO_HOST: device staging of every I/O buffer of te_step / te_observe / te_reset / te_random_actions /
   // te_get_state / te_set_state (one allocation, carved at 256-byte boundaries by te_create)
@@ -835,12 +841,13 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->struct_size != sizeof(te_config)) return fail("te_create: te_config.struct_size mismatch (ABI skew)");
   const int D = cfg->n_pursuers + cfg->n_invaders;
   if (cfg->n_envs < 1) return fail("te_create: n_envs < 1");
-  if (cfg->n_pursuers < 1 || cfg->n_invaders < 1 || D > kMaxD) return fail("te_create: need 1 <= P, 1 <= I, P + I <= 32");
+  if (cfg->n_pursuers < 1 || cfg->n_invaders < 1 || D > kMaxD64 || cfg->n_pursuers > 31) return fail("te_create: need 1 <= P <= 31, 1 <= I, P + I <= 64");
+  if (cfg->initial_invaders < 0 || cfg->invaders_per_round < 0) return fail("te_create: initial_invaders / invaders_per_round must not be negative");
   if (cfg->substeps < 0 || cfg->substeps > 255) return fail("te_create: substeps out of range");
   // substeps == 0: env.step() without physics (the IMU is read from the state as it is, then engagement / reward / termination /
   // waves / observation as usual).  Used to replay the reference's task-logic fixtures on exactly their positions.
   if (cfg->substeps == 0 && cfg->observe_lag != 0) return fail("te_create: substeps == 0 (no physics) needs observe_lag == 0");
-  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_EVALUATION) return fail("te_create: unknown task");
+  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_LEVEL5_DUMB) return fail("te_create: unknown task");
   if (cfg->ground_contact && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: cfg.ground_contact is built for the level4 task family only");
   if (cfg->evaluation && (((uint32_t)cfg->evaluation >> 8) >> cfg->n_pursuers) != 0u) return fail("te_create: cfg.evaluation's driver mask names a pursuer that does not exist");
   if (cfg->evaluation && !(family_of(cfg->task) == FAM_LEVEL4 && cfg->ally_policy == TE_ALLY_BT && !cfg->stacked_obs))
@@ -883,10 +890,16 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (e->family == FAM_LEVEL4) {
     if (cfg->n_pursuers <= 2 && D <= 11) e->engage_regs = 1;
     else if (cfg->n_pursuers <= 6 && D <= 18) e->engage_regs = 2;
+    else if (cfg->n_pursuers <= 7 && D <= 37) e->engage_regs = 5;
   } else if (e->family == FAM_STAGE02) {
     if (cfg->n_pursuers <= 2 && D <= 10) e->engage_regs = 3;
   } else if (e->family == FAM_STAGE01) e->engage_regs = 4;
   if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "lds")) e->engage_regs = 0; }
+  const bool regs_l4 = e->engage_regs == 1 || e->engage_regs == 2 || e->engage_regs == 5;
+  if (D > kMaxD && !(regs_l4 && cfg->stacked_obs && (cfg->agent_scripted || cfg->evaluation)))
+    return bail("te_create: more than 32 drones per env are served for the all-scripted level5 tasks only (te_step_students: stacked_obs + agent_scripted, P <= 7, P + I <= 37)");
+  if ((cfg->agent_scripted || cfg->reward_model != TE_REWARD_EXP03 || !cfg->agent_death_terminates || cfg->initial_invaders != 1 || cfg->invaders_per_round != 1) && !regs_l4)
+    return bail("te_create: agent_scripted / reward_model / agent_death_terminates / the round rule are built into engage_kernel: the level4 task family with P <= 7 and P + I <= 37");
   if (cfg->drone_contact && !(e->engage_regs == 1 || e->engage_regs == 2))
     return bail("te_create: cfg.drone_contact is built into engage_kernel: the level4 task family with P <= 6 and P + I <= 18");
   e->p.dense_min = kDenseMin;
@@ -912,7 +925,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (dwords >= (1ull << 30)) return bail("te_create: n_envs * drones too large for one te_env (state planes are indexed with 32 bits); shard it");
   if (hipMalloc(&e->p.dstate, dwords * 4) != hipSuccess || hipMalloc(&e->p.estate, ewords * 4) != hipSuccess)
     return bail("te_create: hipMalloc failed");
-  if (hipMalloc(&e->p.slot_mask, (size_t)(e->p.Npad / 64) * 4) != hipSuccess || hipMalloc(&e->p.mixed_count, (size_t)(e->p.Npad / 64) * 4) != hipSuccess ||
+  if (hipMalloc(&e->p.slot_mask, (size_t)(e->p.Npad / 64) * 8) != hipSuccess || hipMalloc(&e->p.mixed_count, (size_t)(e->p.Npad / 64) * 4) != hipSuccess ||
       hipMalloc(&e->p.mixed_items, (size_t)(e->p.Npad / 64) * kMixedCap * sizeof(uint16_t)) != hipSuccess)
     return bail("te_create: hipMalloc failed");
   TE_HIP_OR_BAIL(hipMemsetAsync(e->p.mixed_count, 0, (size_t)(e->p.Npad / 64) * 4, nullptr));
@@ -943,6 +956,10 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     e->hs.mask = (uint8_t*)(b + off[9]); e->hs.info = (int32_t*)(b + off[10]); e->hs.blob = (uint32_t*)(b + off[11]);
   }
   e->p.entry_words = TE_RING_ENTRY_WORDS(D);
+  if (cfg->stacked_obs && (cfg->agent_scripted || cfg->evaluation)) {
+    if (hipMalloc(&e->zero_actions, (size_t)e->p.Npad * 16) != hipSuccess) return bail("te_create: hipMalloc failed");
+    TE_HIP_OR_BAIL(hipMemsetAsync(e->zero_actions, 0, (size_t)e->p.Npad * 16, nullptr));
+  }
   if (cfg->stacked_obs) {
     e->stack_lds_bytes = (size_t)stack_lds_rows(D, cfg->n_pursuers) * kEPB * sizeof(uint32_t);
     const size_t snap_bytes = (size_t)snap_words(D, cfg->n_pursuers) * e->p.Npad * 4;
@@ -980,6 +997,7 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   (void)hipFree(e->p.dstate);
   (void)hipFree(e->p.estate);
   (void)hipFree(e->ally_scratch);
+  (void)hipFree(e->zero_actions);
   (void)hipFree(e->hs.base);
   (void)hipFree(e->p.slot_mask); (void)hipFree(e->p.mixed_count); (void)hipFree(e->p.mixed_items);
   (void)hipFree(e->p.stage_tab);
@@ -1093,6 +1111,7 @@ __attribute__((visibility("default"))) int te_observe(te_env* e, float* obs_lida
 }
 static int observe_device(te_env* e, float* obs_lidar, float* obs_inertial, float* obs_last_action, void* stream) {
   if (!e) return fail("te_observe: null env");
+  if (e->p.D > kMaxD) return fail("te_observe: more than 32 drones per env: the observation comes out of te_step_students");
   if ((obs_lidar && ((uintptr_t)obs_lidar & 15)) || (obs_last_action && ((uintptr_t)obs_last_action & 15)))
     return fail("te_observe: obs_lidar and obs_last_action must be 16-byte aligned");
   DeviceGuard guard(e->device);
@@ -1106,7 +1125,7 @@ static int observe_device(te_env* e, float* obs_lidar, float* obs_inertial, floa
 // [N,3,13,26] for te_step, [N,6,3,13,26] (`lidar_words_per_env` = 6084) for te_step_stacked, which also passes `stack`.
 static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t lidar_words_per_env, float* obs_inertial,
                      float* obs_last_action, float* reward, uint8_t* done, int32_t* info, float* terminal_lidar,
-                     float* terminal_inertial, float* terminal_last_action, const StackOut* stack, void* stream) {
+                     float* terminal_inertial, float* terminal_last_action, const StackOut* stack, void* stream, int n_obs = 1) {
   if (!e) return fail("te_step: null env");
   if (!actions || !reward || !done || !info) return fail("te_step: actions, reward, done and info are required");
   if ((e->p.ring != nullptr) != (stack != nullptr))
@@ -1153,8 +1172,12 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   // output comes from stacked_kernel
   StepOut o{reward, done, info, ObsOut{stack ? nullptr : obs_lidar, obs_inertial, obs_last_action},
             ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}};
-  if (e->engage_regs == 1) hipLaunchKernelGGL((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, st, p, actions, o);
-  else if (e->engage_regs == 2) hipLaunchKernelGGL((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  const bool contact = p.cfg.drone_contact != 0;   // its own instantiations: the contact pass would cost every launch ~150 VGPRs
+  if (e->engage_regs == 1 && !contact) hipLaunchKernelGGL((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  else if (e->engage_regs == 1) hipLaunchKernelGGL((engage_kernel<2, 9, true>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  else if (e->engage_regs == 2 && !contact) hipLaunchKernelGGL((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  else if (e->engage_regs == 2) hipLaunchKernelGGL((engage_kernel<6, 12, true>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  else if (e->engage_regs == 5) hipLaunchKernelGGL((engage_kernel<7, 30>), dim3(b2), dim3(64), 0, st, p, actions, o);
   else if (e->engage_regs == 3) hipLaunchKernelGGL((engage_stage02_kernel<2, 8>), dim3(b2), dim3(64), 0, st, p, actions, o);
   else if (e->engage_regs == 4) hipLaunchKernelGGL(engage_stage01_kernel, dim3(b2), dim3(64), 0, st, p, actions, o);
   else launch_by_family(e->family, [&](auto fam) {
@@ -1162,8 +1185,11 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
     else hipLaunchKernelGGL((engage_observe_kernel<decltype(fam)::value>), dim3(b2), dim3(256), e->lds_bytes, st, p, actions, o);
   });
   if (stack) {
-    StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 1};
-    hipLaunchKernelGGL(stacked_kernel, dim3(b2), dim3(kStackThreads), e->stack_lds_bytes, st, sp, *stack);
+    // the first launch pushes this step's ring entries (all wingmen) and serves observer 0; te_step_students adds one launch per further wingman
+    for (int ob = 0; ob < n_obs; ++ob) {
+      StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, ob == 0 ? 1 : 0, ob, n_obs};
+      hipLaunchKernelGGL(stacked_kernel, dim3(b2), dim3(kStackThreads), e->stack_lds_bytes, st, sp, *stack);
+    }
   }
   if (prof) { TE_HIP(hipEventRecord(e->events[e->prof_used + 2], st)); e->prof_used += 3; }
   TE_HIP(hipGetLastError());
@@ -1208,10 +1234,52 @@ __attribute__((visibility("default"))) int te_step_stacked(te_env* e, const floa
                    terminal_inertial, terminal_last_action, &so, stream);
 }
 
+// Level5DumbMultiObs.compute_info rows of every pursuer after the step (level5_dumb_multiobs.py:116-150): normalised IMU + gun state,
+// the behaviour tree's command of this step as an action (unit direction, speed: loyalwingman_navigator.py:301,325,350), armed flag
+__global__ __launch_bounds__(256) void students_rows_kernel(Params p, const uint8_t* __restrict__ done, float* __restrict__ inertial,
+                                                            float* __restrict__ last_action, uint8_t* __restrict__ active) {
+  const int i = blockIdx.x * 256 + threadIdx.x, P = p.cfg.n_pursuers;
+  if (i >= p.N * P) return;
+  const int s = i / p.N, env = i - s * p.N;   // slot-major: consecutive threads = consecutive envs of one plane
+  const GView v{p.dstate, p.estate, p.D, p.Npad, env, P};
+  const size_t row = (size_t)env * P + s;
+  float in[TE_OBS_INERTIAL_WORDS];
+  inertial_obs(p.cfg, v, v.egi(TE_E_STEP), in, s);
+#pragma unroll
+  for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) inertial[row * TE_OBS_INERTIAL_WORDS + k] = in[k];
+  const bool armed = v.gi(TE_D_ARMED, s) != 0;
+  const bool fresh = done[env] != 0 && p.cfg.auto_reset;   // the reset observation: nobody has been commanded yet
+  float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (armed && !fresh) {
+    const float sp = p.cfg.ally_speed;
+    a = make_float4(v.gf(TE_D_SETPOINT, s) / sp, v.gf(TE_D_SETPOINT + 1, s) / sp, v.gf(TE_D_SETPOINT + 3, s) / sp, sp);
+  }
+  reinterpret_cast<float4*>(last_action)[row] = a;
+  active[row] = armed ? 1 : 0;
+}
+
+__attribute__((visibility("default"))) int te_step_students(te_env* e, float* stacked, uint8_t* mask, float* inertial, float* last_action,
+                                                            uint8_t* active, float* reward, uint8_t* done, int32_t* info, void* stream) {
+  if (!e) return fail("te_step_students: null env");
+  if (!e->p.ring || !all_scripted(e->p.cfg)) return fail("te_step_students: needs cfg.stacked_obs and an all-scripted task (cfg.agent_scripted or cfg.evaluation)");
+  if (!stacked || !mask || !inertial || !last_action || !active || !reward || !done || !info) return fail("te_step_students: every output buffer is required");
+  if (((uintptr_t)stacked & 15) || ((uintptr_t)last_action & 15) || ((uintptr_t)info & 15)) return fail("te_step_students: stacked, last_action and info must be 16-byte aligned");
+  if (!e->zero_actions) return fail("te_step_students: internal error: no action buffer");
+  const int P = e->p.cfg.n_pursuers;
+  const StackOut so{stacked, mask, nullptr, nullptr};
+  if (step_impl(e, e->zero_actions, stacked, (size_t)P * TE_OBS_STACKED_WORDS, nullptr, nullptr, reward, done, info, nullptr, nullptr, nullptr, &so, stream, P)) return 1;
+  DeviceGuard guard(e->device);
+  const int n = e->p.N * P;
+  hipLaunchKernelGGL(students_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->p, done, inertial, last_action, active);
+  TE_HIP(hipGetLastError());
+  return 0;
+}
+
 __attribute__((visibility("default"))) int te_observe_stacked(te_env* e, float* obs_stacked, uint8_t* obs_mask, float* obs_inertial,
                                                               float* obs_last_action, void* stream) {
   if (!e) return fail("te_observe_stacked: null env");
   if (!e->p.ring) return fail("te_observe_stacked: this te_env was created without cfg.stacked_obs");
+  if (e->p.D > kMaxD) return fail("te_observe_stacked: more than 32 drones per env: the observation comes out of te_step_students");
   if (!obs_stacked || !obs_mask || ((uintptr_t)obs_stacked & 15)) return fail("te_observe_stacked: obs_stacked (16-byte aligned) and obs_mask are required");
   DeviceGuard guard(e->device);
   hipStream_t st = (hipStream_t)stream;
@@ -1220,7 +1288,7 @@ __attribute__((visibility("default"))) int te_observe_stacked(te_env* e, float* 
   hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, obs_stacked, (size_t)p.N * TE_OBS_STACKED_WORDS);
   hipLaunchKernelGGL(snapshot_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, p);
   hipLaunchKernelGGL(observe_kernel, dim3(blocks), dim3(256), e->lds_bytes, st, p, ObsOut{nullptr, obs_inertial, obs_last_action});
-  StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 0};
+  StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 0, 0, 1};
   hipLaunchKernelGGL(stacked_kernel, dim3(blocks), dim3(kStackThreads), e->stack_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
   TE_HIP(hipGetLastError());
   return 0;

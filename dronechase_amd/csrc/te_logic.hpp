@@ -14,7 +14,8 @@
 namespace te {
 
 constexpr int kEPB = 64;   // envs per engage/observe block = one wavefront of logic lanes
-constexpr int kMaxD = 32;
+constexpr int kMaxD = 32;     // drones per env the LDS kernels (engage_observe_kernel, observe_kernel, the ally kernels) serve: 32-bit slot masks
+constexpr int kMaxD64 = 64;   // ... and what the state layout, the sub-step kernel, engage_kernel<7, 30> and stacked_kernel serve (Level5DumbMultiObs: 7 + 30)
 enum Family { FAM_LEVEL4 = 0, FAM_STAGE01 = 1, FAM_STAGE02 = 2 };
 
 // ------------------------------------------------------------------------------------------------
@@ -164,7 +165,7 @@ TE_DEV void gun_state(const te_config& c, int munition, int last_fired, int step
 }
 template <class V> TE_DEV uint32_t armed_mask(const V& v) {
   uint32_t m = 0;
-  for (int s = 0; s < v.D; ++s) m |= (v.gi(TE_D_ARMED, s) ? 1u : 0u) << s;
+  for (int s = 0; s < v.D && s < 32; ++s) m |= (v.gi(TE_D_ARMED, s) ? 1u : 0u) << s;   // (slots 32.. : SnapRows::armed_hi, engage_kernel's 64-bit masks)
   return m;
 }
 
@@ -189,11 +190,18 @@ TE_DEV V3 stage02_position(float r, float r_max, float u_r, float u_theta, float
   return V3{radius * sph * cth, radius * sph * sth, radius * cph};
 }
 
+// invaders armed in round r: `round` of them in the exp tasks (exp03_vFinal_task.py:180-196); min((r - 1) * per_round + initial, max) in
+// Level5DumbMultiObjectTask (level5_dumb_multiobject_task.py:173-184)
+TE_DEV int invaders_in_round(const te_config& c, int round) { return min((round - 1) * c.invaders_per_round + c.initial_invaders, c.n_invaders); }
+// Evaluation_Task / Level5DumbMultiObjectTask: pursuer 0 obeys the behaviour tree like the other wingmen
+__host__ __device__ __forceinline__ bool all_scripted(const te_config& c) { return c.evaluation != 0 || c.agent_scripted != 0; }
+template <class V> TE_DEV void set_snap_mask(const V& v, uint64_t m) { v.esi(TE_E_SNAP_MASK, (int)(uint32_t)m); v.esi(TE_E_SNAP_MASK_HI, (int)(uint32_t)(m >> 32)); }
+template <class V> TE_DEV uint64_t get_snap_mask(const V& v) { return (uint64_t)(uint32_t)v.egi(TE_E_SNAP_MASK) | ((uint64_t)(uint32_t)v.egi(TE_E_SNAP_MASK_HI) << 32); }
 // ------------------------------------------------------------------------------------------------
 // offsets over the snapshot mask (level4/components/entities_management/offsets_handler.py)
 // ------------------------------------------------------------------------------------------------
 // closest invader (over mask) to pursuer p, and its distance (identify_closest_invader, :256-281)
-template <class V> TE_DEV int closest_invader(const V& v, uint32_t mask, int p, float& dmin) {
+template <class V> TE_DEV int closest_invader(const V& v, uint64_t mask, int p, float& dmin) {
   int best = -1; dmin = 0.0f;
   for (int j = v.P; j < v.D; ++j) {
     if (!((mask >> j) & 1u)) continue;
@@ -203,7 +211,7 @@ template <class V> TE_DEV int closest_invader(const V& v, uint32_t mask, int p, 
   return best;
 }
 // closest pursuer (over mask) to invader j (identify_closest_pursuer, :228-254)
-template <class V> TE_DEV int closest_pursuer(const V& v, uint32_t mask, int j) {
+template <class V> TE_DEV int closest_pursuer(const V& v, uint64_t mask, int j) {
   int best = -1; float bd = 0.0f;
   for (int p = 0; p < v.P; ++p) {
     if (!((mask >> p) & 1u)) continue;
@@ -213,8 +221,8 @@ template <class V> TE_DEV int closest_pursuer(const V& v, uint32_t mask, int j) 
   return best;
 }
 // closest other pursuer to pursuer p (identify_closest_ally, :167-190)
-template <class V> TE_DEV int closest_ally(const V& v, uint32_t mask, int p) {
-  if (!((mask >> p) & 1u) || __popc(mask & ((1u << v.P) - 1u)) <= 1) return -1;
+template <class V> TE_DEV int closest_ally(const V& v, uint64_t mask, int p) {
+  if (!((mask >> p) & 1u) || __popc((uint32_t)mask & ((1u << v.P) - 1u)) <= 1) return -1;
   V3 me = obs_pos(v, p);
   int best = -1; float bd = 0.0f;
   for (int a = 0; a < v.P; ++a) {
@@ -290,11 +298,11 @@ TE_DEV bool driven_externally(const te_config& c, int s) {
 template <class V> TE_DEV void prepare_slot(const te_config& c, const V& v, int s) {
   const int Pn = c.n_pursuers;
   // Evaluation_Task.drive_lw (evaluation_task.py:257-275) flies EVERY armed pursuer, pursuer 0 included
-  if ((s == 0 && !c.evaluation) || s >= Pn || !v.gi(TE_D_ARMED, s)) return;
-  const uint32_t S = (uint32_t)v.egi(TE_E_SNAP_MASK);
+  if ((s == 0 && !all_scripted(c)) || s >= Pn || !v.gi(TE_D_ARMED, s)) return;
+  const uint64_t S = get_snap_mask(v);
   // drive_loyalwingmen: get_armed_pursuers()[1:] (exp03_vFinal_task.py:238-244): with the agent dead the
   // first armed ally is the one that is skipped
-  if (!c.evaluation && !v.gi(TE_D_ARMED, 0)) {
+  if (!all_scripted(c) && !v.gi(TE_D_ARMED, 0)) {
     int first = -1;
     for (int a = 1; a < Pn; ++a) if (v.gi(TE_D_ARMED, a)) { first = a; break; }
     if (s == first) return;
@@ -324,7 +332,7 @@ template <class V> TE_DEV void publish_pursuer_ref(const V& v, int s) {
 }
 template <class V> TE_DEV void prepare_level4_commands(const te_config& c, const V& v) {
   for (int s = 0; s < c.n_pursuers; ++s) publish_pursuer_ref(v, s);
-  for (int s = c.evaluation ? 0 : 1; s < c.n_pursuers; ++s) prepare_slot(c, v, s);
+  for (int s = all_scripted(c) ? 0 : 1; s < c.n_pursuers; ++s) prepare_slot(c, v, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,7 +350,7 @@ template <class V> TE_DEV void level4_spawn_slot(const te_config& c, const V& v,
   if (s >= Pn) {
     disarm(v, s);
     const int i = s - Pn;
-    if (i < round && i < c.n_invaders) {
+    if (i < invaders_in_round(c, round)) {
       U4 r = env_rng(c, v.env, RNG_SPAWN_INVADER, (uint32_t)s, 0, episode, (uint32_t)round);
       respawn_armed(c, v, s, level4_position(c, c.born_radius, u01(r.x), u01(r.y)));
     }
@@ -358,16 +366,16 @@ template <class V> TE_DEV void level4_spawn_slot(const te_config& c, const V& v,
   if (s >= Pn || reset) v.si(TE_D_NAV_STATE, s, TE_NAV_WAIT);
 }
 // armed mask once every slot has been through level4_spawn_slot
-template <class V> TE_DEV uint32_t level4_mask_after_spawn(const te_config& c, const V& v, int round, bool reset) {
+template <class V> TE_DEV uint64_t level4_mask_after_spawn(const te_config& c, const V& v, int round, bool reset) {
   const int Pn = c.n_pursuers;
-  uint32_t m = 0;
-  for (int p = 0; p < Pn; ++p) m |= ((reset || v.gi(TE_D_ARMED, p)) ? 1u : 0u) << p;
-  const int n = round < c.n_invaders ? round : c.n_invaders;
-  return m | (((1u << n) - 1u) << Pn);
+  uint64_t m = 0;
+  for (int p = 0; p < Pn; ++p) m |= (uint64_t)((reset || v.gi(TE_D_ARMED, p)) ? 1u : 0u) << p;
+  const int n = invaders_in_round(c, round);
+  return m | ((((uint64_t)1 << n) - 1u) << Pn);
 }
 template <class V> TE_DEV void level4_setup_round(const te_config& c, const V& v, int round, uint32_t episode) {
   for (int s = 0; s < v.D; ++s) level4_spawn_slot(c, v, s, round, episode, false);
-  v.esi(TE_E_SNAP_MASK, (int)level4_mask_after_spawn(c, v, round, false));
+  set_snap_mask(v, level4_mask_after_spawn(c, v, round, false));
 }
 // the env-record half of Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146)
 template <class V> TE_DEV uint32_t level4_reset_record(const te_config& c, const V& v) {
@@ -378,7 +386,7 @@ template <class V> TE_DEV uint32_t level4_reset_record(const te_config& c, const
   v.esf(TE_E_LAST_DIST, c.dome_radius);
 #pragma unroll
   for (int k = 0; k < 4; ++k) v.esf(TE_E_LAST_ACTION + k, 0.0f);
-  v.esi(TE_E_SNAP_MASK, (int)level4_mask_after_spawn(c, v, 1, true));
+  set_snap_mask(v, level4_mask_after_spawn(c, v, 1, true));
   return episode;
 }
 template <class V> TE_DEV void level4_reset_env(const te_config& c, const V& v, bool prepare = true) {
@@ -820,7 +828,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
     if (!term && armed_invaders == 0 && armed_pursuers > 0) {
       int next = round + (round < c.n_rounds ? 1 : c.n_rounds);  // advance_round (:155-175)
       v.esi(TE_E_ROUND, next);
-      v.esi(TE_E_SNAP_MASK, (int)level4_mask_after_spawn(c, v, next, false));
+      set_snap_mask(v, level4_mask_after_spawn(c, v, next, false));
       v.sm[v.at(v.r.task())] = (uint32_t)next;  // the D slots are respawned by the whole block (spawn phase)
       v.pre_valid = false;
     }

@@ -28,9 +28,10 @@ struct SnapRows {
   TE_DEV int step() const { return armed() + 1; }      // RL step of the observation (before any auto-reset)
   TE_DEV int episode() const { return armed() + 2; }
   TE_DEV int done() const { return armed() + 3; }      // the env auto-resets in this step
-  TE_DEV int total() const { return armed() + 4; }
+  TE_DEV int armed_hi() const { return armed() + 4; }  // bits 32.. of the armed mask (more than 32 drones per env)
+  TE_DEV int total() const { return armed() + 5; }
 };
-__host__ __device__ inline int snap_words(int D, int P) { return 3 * D + 3 * P + 4; }
+__host__ __device__ inline int snap_words(int D, int P) { return 3 * D + 3 * P + 5; }
 
 struct StackOut { float* stacked; uint8_t* mask; float* t_stacked; uint8_t* t_mask; };
 
@@ -44,9 +45,10 @@ struct StackRows {
   TE_DEV int step() const { return armed() + 1; }
   TE_DEV int episode() const { return armed() + 2; }
   TE_DEV int done() const { return armed() + 3; }
+  TE_DEV int armed_hi() const { return armed() + 4; }         // bits 32.. of the armed mask (more than 32 drones per env)
   // phase (1) uses feat + work, phase (3) re-uses the same rows for the four neighbour lists (157 >= 136 rows at D = 18):
   // the block stays below 80 KB of LDS, i.e. two blocks per CU
-  TE_DEV int feat() const { return armed() + 4; }             // 4*D : r_hat, theta, phi, cell of drone j seen from wingman p
+  TE_DEV int feat() const { return armed() + 5; }             // 4*D : r_hat, theta, phi, cell of drone j seen from wingman p
   TE_DEV int work() const { return feat() + 4 * D; }          // 5*F : closer-wins working list (cell, r_hat, theta, phi, meta)
   TE_DEV int nb_k() const { return feat(); }                  // 4 * 2*F (aliases feat + work): cell | type << 16, r_hat
   TE_DEV int own_n() const { return work() + 5 * F(); }       // 1   : kept features of the agent's own sphere
@@ -59,8 +61,8 @@ struct StackRows {
   TE_DEV int opos() const { return nb_n() + 4; }              // 5   : output position of own / neighbour k (or 0xFF)
   TE_DEV int total() const { return opos() + 5; }
 };
-__host__ __device__ inline int stack_lds_rows(int D, int P) { return 3 * D + 4 * P + 4 + 4 * D + 5 * (D - 1) + 1 + 2 * (D - 1) + 4 + 4 + 5; }
-static_assert(4 * 32 + 5 * 31 >= 8 * 31, "the neighbour lists must fit in feat + work");
+__host__ __device__ inline int stack_lds_rows(int D, int P) { return 3 * D + 4 * P + 5 + 4 * D + 5 * (D - 1) + 1 + 2 * (D - 1) + 4 + 4 + 5; }
+static_assert(4 * 32 + 5 * 31 >= 8 * 31 && 4 * 64 + 5 * 63 >= 8 * 63, "the neighbour lists must fit in feat + work");
 
 TE_DEV V3 rotate_by(Q4 q, V3 v) { return mul(rotation(q), v); }  // pybullet rotateVector
 TE_DEV Q4 inverse_of(Q4 q) {  // LidarMath._invert_quaternion (lidar_math.py:40-51)
@@ -87,12 +89,12 @@ TE_DEV uint32_t load_fresh(const uint32_t* p) { return __builtin_nontemporal_loa
 // n distinct armed wingmen (the agent included) without replacement; an age ~ U{1..9} each; a uniform permutation of
 // the six (sphere, valid) pairs.  16 Philox words keyed (STACK, slot 0, sub 0..3, episode, step); an integer in
 // [0, k) is (word * k) >> 32.  The test checker restates exactly this sequence.
-TE_DEV void draw_stack(const te_config& c, int env, uint32_t episode, uint32_t step, uint32_t armed_pursuers, int P, int& n,
+TE_DEV void draw_stack(const te_config& c, int env, int observer, uint32_t episode, uint32_t step, uint32_t armed_pursuers, int P, int& n,
                        uint32_t& who, uint32_t& age, uint32_t& perm) {
   uint32_t w[16];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const U4 r = env_rng(c, env, RNG_STACK, 0u, (uint32_t)k, episode, step);
+    const U4 r = env_rng(c, env, RNG_STACK, (uint32_t)observer, (uint32_t)k, episode, step);   // every observer draws its own neighbourhood
     w[4 * k] = r.x; w[4 * k + 1] = r.y; w[4 * k + 2] = r.z; w[4 * k + 3] = r.w;
   }
   uint32_t cand = armed_pursuers;  // candidates as a bit set; "position i of the array" = i-th set bit still unused
@@ -100,7 +102,7 @@ TE_DEV void draw_stack(const te_config& c, int env, uint32_t episode, uint32_t s
   const int want = 1 + (int)(((uint64_t)w[0] * 4u) >> 32);
   n = want < nc ? want : nc;
   // partial Fisher-Yates over the candidates in slot order, on an explicit small array (nc <= 32)
-  uint8_t arr[kMaxD];
+  uint8_t arr[kMaxD64];
   int m = 0;
   for (int p = 0; p < P; ++p) if ((cand >> p) & 1u) arr[m++] = (uint8_t)p;
   who = 0u; age = 0u;
@@ -127,6 +129,8 @@ struct StackParams {
   uint32_t* ring;
   int N, Npad, D, entry_words;
   int push;              // 1: te_step_stacked (push this step's entries, clear the ring of auto-reset envs); 0: te_observe_stacked
+  int observer;          // whose FusedLIDAR.read_data this launch serves: 0 = the agent; te_step_students launches it once per wingman
+  int n_obs;             // observers per env in the output buffers: 1 ([N,6,...]) or P ([N,P,6,...], te_step_students)
 };
 
 constexpr int kStackThreads = 512;  // 8 waves: the block's LDS (73 KB at D = 18) allows two blocks per CU, i.e. 4 waves per SIMD (+ 9 % env-steps/s over 256 threads)
@@ -138,6 +142,8 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
   const SnapRows sr{D, P};
   const int env0 = blockIdx.x * kEPB, nvalid = min(kEPB, p.N - env0);
   const int tid = threadIdx.x, lane = tid & (kEPB - 1);
+  const int ob = p.observer;
+  auto orow = [&](int l) { return (size_t)(env0 + l) * (size_t)p.n_obs + (size_t)ob; };   // row of (env, observer) in the output buffers
   auto row = [&](int rr, int l) -> uint32_t& { return sm[rr * kEPB + l]; };
   auto rowf = [&](int rr, int l) { return __uint_as_float(sm[rr * kEPB + l]); };
   // ---- stage the snapshot (coalesced: planes are env-fastest)
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
     for (int pp = 0; pp < P; ++pp) {
       for (int it = tid; it < kEPB * D; it += blockDim.x) {
         const int l = it & (kEPB - 1), j = it / kEPB;
-        const uint32_t A = row(r.armed(), l);
+        const uint64_t A = (uint64_t)row(r.armed(), l) | ((uint64_t)row(r.armed_hi(), l) << 32);
         if (j == pp || !((A >> j) & 1u) || !((A >> pp) & 1u)) { row(r.feat() + 3 * D + j, l) = 0xFFFFFFFFu; continue; }
         const V3 local = rotate_by(inverse_of(quat_of(pp, l)), sub(pos_of(j, l), pos_of(pp, l)));
         float rhat, th, ph; int cell;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
           *reinterpret_cast<uint4*>(ent) = make_uint4((uint32_t)step, n, __float_as_uint(me.x), __float_as_uint(me.y));
           *reinterpret_cast<uint4*>(ent + 4) = make_uint4(__float_as_uint(me.z), __float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z));
           *reinterpret_cast<uint4*>(ent + 8) = make_uint4(__float_as_uint(q.w), 0u, 0u, 0u);
-          if (pp == 0) row(r.own_n(), l) = n;
+          if (pp == ob) row(r.own_n(), l) = n;
         } else if (row(lead + j, l)) {
           uint32_t at = 0u;
           for (int k = 0; k < j; ++k) at += row(lead + k, l);
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
           const uint32_t meta = (uint32_t)(w < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) | ((uint32_t)w << 8);
           const uint4 f = make_uint4(row(r.feat() + 0 * D + w, l), row(r.feat() + 1 * D + w, l), row(r.feat() + 2 * D + w, l), meta);
           *reinterpret_cast<uint4*>(ent + TE_RING_HEADER_WORDS + 4 * at) = f;   // slots >= n keep stale words: never read
-          if (pp == 0) {  // the agent keeps (cell, type, r_hat) of its own sphere for the patch phase
+          if (pp == ob) {  // the observer keeps (cell, type, r_hat) of its own sphere for the patch phase
             row(r.own_k() + 2 * at, l) = row(r.feat() + 3 * D + j, l) | ((meta & 0xFFu) << 16); row(r.own_k() + 2 * at + 1, l) = f.x;
           }
         }
@@ -233,8 +239,8 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
     const int step = (int)row(r.step(), l);
     bool own_ok = l < nvalid && step >= 1;
     if (own_ok) {
-      const uint32_t* own = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), 0, step);
-      if (p.push) own_ok = (row(r.armed(), l) & 1u) != 0u;  // pushed above iff the agent is armed
+      const uint32_t* own = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), ob, step);
+      if (p.push) own_ok = ((row(r.armed(), l) >> ob) & 1u) != 0u;  // pushed above iff the observer is armed
       else {  // te_observe_stacked: the own sphere comes back out of the ring
         own_ok = (int)load_fresh(own) == step;
         if (own_ok) {
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
     }
     if (own_ok) {
       int nn;
-      draw_stack(c, env0 + l, row(r.episode(), l), (uint32_t)step, row(r.armed(), l) & ((1u << P) - 1u), P, nn, who, age, perm);
+      draw_stack(c, env0 + l, ob, row(r.episode(), l), (uint32_t)step, row(r.armed(), l) & ((1u << P) - 1u), P, nn, who, age, perm);
       n = (uint32_t)nn;
     } else row(r.own_n(), l) = 0xFFFFFFFFu;  // _build_valid_spheres returns [] without an own snapshot (fused_lidar.py:91-96)
     row(r.dn(), l) = n; row(r.dwho(), l) = who; row(r.dage(), l) = age; row(r.dperm(), l) = perm;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
       const int s = step - (a - 1);
       const uint32_t* nb = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), q, s > 0 ? s : 0);
       if (s >= 1 && (int)load_fresh(nb) == s) {  // get_snapshot -> None otherwise (lidar_buffer.py:152-154)
-        const uint32_t* own = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), 0, step);
+        const uint32_t* own = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), ob, step);
         const V3 pn{__uint_as_float(load_fresh(nb + 2)), __uint_as_float(load_fresh(nb + 3)), __uint_as_float(load_fresh(nb + 4))};
         const Q4 qn{__uint_as_float(load_fresh(nb + 5)), __uint_as_float(load_fresh(nb + 6)), __uint_as_float(load_fresh(nb + 7)), __uint_as_float(load_fresh(nb + 8))};
         const V3 po{__uint_as_float(load_fresh(own + 2)), __uint_as_float(load_fresh(own + 3)), __uint_as_float(load_fresh(own + 4))};
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
         for (int f = 0; f < cnt; ++f) {
           const uint32_t* ff = nb + TE_RING_HEADER_WORDS + 4 * f;
           const uint32_t meta = load_fresh(ff + 3);
-          if ((int)((meta >> 8) & 0xFFu) == 0) continue;  // synthetic echo of the agent itself (lidar_math.py:228-232)
+          if ((int)((meta >> 8) & 0xFFu) == ob) continue;  // synthetic echo of the observer itself (lidar_math.py:228-232)
           const float R = __uint_as_float(load_fresh(ff)) * c.lidar_radius, th = __uint_as_float(load_fresh(ff + 1)), ph = __uint_as_float(load_fresh(ff + 2));
           float st, ct, sp, cp;
           sincosf(th, &st, &ct); sincosf(ph, &sp, &cp);
@@ -319,8 +325,8 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
       if (sidx[s] >= 0) for (int i = 0; i < TE_STACK_SPHERES; ++i) if ((int)((perm >> (4 * i)) & 0xFu) == sidx[s]) at = (uint32_t)i;
       row(r.opos() + s, l) = at;
     }
-    if (M) for (int i = 0; i < TE_STACK_SPHERES; ++i) M[(size_t)(env0 + l) * TE_STACK_SPHERES + i] = (any && (int)((perm >> (4 * i)) & 0xFu) < nv) ? 1 : 0;
-    if (done && o.mask) for (int i = 0; i < TE_STACK_SPHERES; ++i) o.mask[(size_t)(env0 + l) * TE_STACK_SPHERES + i] = 0;  // reset observation
+    if (M) for (int i = 0; i < TE_STACK_SPHERES; ++i) M[orow(l) * TE_STACK_SPHERES + i] = (any && (int)((perm >> (4 * i)) & 0xFu) < nv) ? 1 : 0;
+    if (done && o.mask) for (int i = 0; i < TE_STACK_SPHERES; ++i) o.mask[orow(l) * TE_STACK_SPHERES + i] = 0;  // reset observation
   }
   // ---- (4b) terminal tiles of auto-reset envs are not pre-filled: ones first (rare, block-uniform test)
   const bool lane_done = tid < kEPB && tid < nvalid && row(r.done(), tid) != 0u;
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
     if (o.t_stacked)
       for (int l = 0; l < nvalid; ++l) {
         if (!row(r.done(), l)) continue;
-        float* base = o.t_stacked + (size_t)(env0 + l) * TE_OBS_STACKED_WORDS;
+        float* base = o.t_stacked + orow(l) * TE_OBS_STACKED_WORDS;
         for (int e = tid; e < TE_OBS_STACKED_WORDS; e += blockDim.x) base[e] = 1.0f;
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
     const uint32_t at = row(r.opos() + sphere_slot, l);
     float* basep = row(r.done(), l) ? o.t_stacked : o.stacked;
     if (at == 0xFFu || !basep) return nullptr;
-    return basep + (size_t)(env0 + l) * TE_OBS_STACKED_WORDS + (size_t)at * TE_OBS_LIDAR_WORDS;
+    return basep + orow(l) * TE_OBS_STACKED_WORDS + (size_t)at * TE_OBS_LIDAR_WORDS;
   };
   for (int it = tid; it < kEPB * (D - 1); it += blockDim.x) {  // own sphere: time = 1/10 (perception_snapshot.py:36-37)
     const int l = it & (kEPB - 1), f = it / kEPB;

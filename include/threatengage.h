@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TE_ABI_VERSION 4
+#define TE_ABI_VERSION 5
 
 /* ---- tasks (reference env class each one mirrors) ----------------------- */
 enum {
@@ -44,6 +44,10 @@ enum {
                           12 invaders and the FusedLIDAR stacked-sphere observation (te_step_stacked) */
   TE_TASK_EXP05 = 7,   /* level4/exp05_vFinal_environment.py + tasks/exp05_vFinal_task.py: exp03 with the ally driven by a
                           second policy (drive_lw_rl_agent, :252-260): te_observe_ally / te_set_ally_actions */
+  TE_TASK_LEVEL5_DUMB = 9, /* threatsense/level5/level5_dumb_multiobs.py + tasks/level5_dumb_multiobject_task.py: the imitation-data
+                          collector's environment — 7 wingmen ALL flown by the behaviour tree (the agent too, :256-266), 30 invader slots
+                          of which min(4 + round, 30) are armed in a round (:173-184), 26 rounds, its own reward (:452-553) and
+                          termination (:555-612); the observation is the stacked one of EVERY armed wingman (te_step_students) */
   TE_TASK_EVALUATION = 8 /* level4/evaluation_environment.py + tasks/evaluation_task.py with behaviour-tree drivers only
                           (apps/threatengage_runner/stage03/experiments/01/evaluation_exp01_1bt_app_ready.py): cfg.evaluation = 1,
                           n_pursuers = number of drivers (default 1) */
@@ -180,6 +184,16 @@ typedef struct te_config {
                              for armed drones only, quadcopter.py:484-496): inelastic impulse along the line of centres at
                              the end of each sub-step, equal masses, no friction, no contact torque */
   float contact_radius;   /* 0.06: radius of the cf2x collision cylinder (unverified) */
+  /* ---- round rule and the switches Level5DumbMultiObjectTask needs (ABI 5) ---- */
+  int32_t initial_invaders;   /* 1: invaders armed in round r = min((r - 1) * invaders_per_round + initial_invaders, n_invaders): */
+  int32_t invaders_per_round; /* 1:   Task.setup_round arms `round` of them (exp03_vFinal_task.py:180-196); the dumb multi-object task
+                                 starts with 5 (level5_dumb_multiobject_task.py:87-90,173-184) */
+  int32_t agent_scripted;     /* 1: pursuer 0 obeys the behaviour tree like the other wingmen and te_step's actions are ignored
+                                 (level5_dumb_multiobject_task.py:256-266; implied by cfg.evaluation) */
+  int32_t reward_model;       /* TE_REWARD_EXP03 (0): exp03_vFinal_task.py:423-515; TE_REWARD_L5_DUMB (1): level5_dumb_multiobject_task.py:452-553
+                                 (reload-distance shaping, weighted kills / deaths, bounded border term, clipped to +-3000) */
+  int32_t agent_death_terminates; /* 1: the episode ends when pursuer 0 is disarmed (training tasks, exp03_vFinal_task.py:556-561);
+                                 0: it goes on (level5_dumb_multiobject_task.py:600-606 has the test commented out) */
   int32_t quad_preset;    /* which table te_config_default / te_quad_preset filled `quad` with: TE_QUAD_CF2X_RECALLED (0) or
                              TE_QUAD_CF2X_RECORDED_FIT (1).  Informational: the kernels read `quad` only */
 
@@ -187,6 +201,7 @@ typedef struct te_config {
 } te_config;
 
 enum { TE_IO_DEVICE = 0, TE_IO_HOST = 1 };
+enum { TE_REWARD_EXP03 = 0, TE_REWARD_L5_DUMB = 1 };
 /* quadrotor parameter presets (te_quad_preset).  RECALLED = PyFlyt 0.11.1's cf2x.yaml / cf2x.urdf as recorded in SURVEY.md
  * Appendix B (the default of every task); RECORDED_FIT = the same table with the smallest change that reproduces the only
  * PyBullet-made numbers in the reference tree (io_data0.h5: seven wingmen, two steps after a respawn) within its motor-noise
@@ -242,7 +257,7 @@ enum {
   TE_E_EPISODE = 8,      /* i32 episode counter (RNG stream selector) */
   TE_E_LAST_ACTION = 9,  /* 4 f32 */
   TE_E_PREV_SNAP_MIN = 13, /* f32 stage02: last_closest_pursuer_to_invader_distance */
-  TE_E_SPARE = 14,
+  TE_E_SNAP_MASK_HI = 14,/* i32 bits 32..63 of the snapshot mask (more than 32 drones per env: TE_TASK_LEVEL5_DUMB has 37) */
   TE_ENV_WORDS = 16
 };
 
@@ -297,6 +312,17 @@ int te_step_stacked(te_env* env, const float* actions, float* obs_stacked, uint8
                     uint8_t* terminal_mask, float* terminal_inertial, float* terminal_last_action, void* stream);
 int te_observe_stacked(te_env* env, float* obs_stacked, uint8_t* obs_mask, float* obs_inertial, float* obs_last_action,
                        void* stream);
+
+/* Level5DumbMultiObs.step + compute_info (threatsense/level5/level5_dumb_multiobs.py:116-150): one env.step in which every wingman is
+ * scripted, returning the STUDENT observation of every pursuer and the teacher's action for it (the collector keeps the rows of the armed
+ * ones, apps/threatsense_runner/collect_and_save.py:99-127):
+ *   stacked [N,P,6,3,13,26] f32, mask [N,P,6] u8, inertial [N,P,15] f32 (normalised IMU + gun state of pursuer p),
+ *   last_action [N,P,4] f32 = the behaviour tree's command of this step (direction, magnitude: pursuer.last_action = the teacher's
+ *   action), active [N,P] u8 = pursuer p is armed after the step (its row is one the reference emits); reward / done / info as te_step.
+ * Needs cfg.stacked_obs and cfg.agent_scripted (or cfg.evaluation).  Envs that auto-reset come back with the reset observation (empty
+ * spheres, zero masks); there are no terminal buffers (the collector has no use for them). */
+int te_step_students(te_env* env, float* stacked, uint8_t* mask, float* inertial, float* last_action, uint8_t* active, float* reward,
+                     uint8_t* done, int32_t* info, void* stream);
 
 /* exp05 (cfg.ally_policy == TE_ALLY_EXTERNAL): the two halves of Exp05_vFinal_Task.drive_lw_rl_agent
  * (exp05_vFinal_task.py:252-260), which the reference runs in on_step_start, i.e. BEFORE the physics of a step:

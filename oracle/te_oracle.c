@@ -31,7 +31,7 @@
 typedef OTE_REAL real;
 
 #define OTE_PI ((real)3.14159265358979323846)
-#define OTE_MAX_DRONES 32
+#define OTE_MAX_DRONES 64
 
 #if defined(__GNUC__)
 #define OTE_API __attribute__((visibility("default")))
@@ -60,7 +60,7 @@ typedef struct {
   int32_t step, max_step, round;
   real last_dist;
   int32_t agent_kills, allies_kills, deads;
-  uint32_t snap_mask;
+  uint64_t snap_mask; /* bit s = drone s armed when the offsets were last computed (blob: TE_E_SNAP_MASK + TE_E_SNAP_MASK_HI) */
   int32_t episode;
   real last_action[4];
   real prev_snap_min;
@@ -80,6 +80,8 @@ typedef struct ote_env {
   real* margin_stack; /* [N] smallest angular distance (rad) of any binned feature to a LIDAR cell boundary, last step */
   /* outputs of the step in flight (set by ote_step_stacked, NULL otherwise) */
   float* out_stacked; uint8_t* out_mask; float* out_t_stacked; uint8_t* out_t_mask;
+  /* ote_step_students: [N,P,...] outputs of the step in flight */
+  float* st_stacked; uint8_t* st_mask; float* st_inertial; float* st_last_action; uint8_t* st_active;
 } ote_env;
 
 /* ------------------------------------------------------------------------- */
@@ -530,7 +532,7 @@ static real dist3(const real a[3], const real b[3]) {
   return norm3(d);
 }
 /* identify_closest_pursuer (offsets_handler.py:228-254): closest pursuer in the snapshot */
-static int closest_pursuer(const te_config* c, const ote_drone* dr, uint32_t mask, int inv_slot) {
+static int closest_pursuer(const te_config* c, const ote_drone* dr, uint64_t mask, int inv_slot) {
   int best = -1; real bd = 0;
   for (int p = 0; p < c->n_pursuers; ++p) {
     if (!((mask >> p) & 1u)) continue;
@@ -540,7 +542,7 @@ static int closest_pursuer(const te_config* c, const ote_drone* dr, uint32_t mas
   return best;
 }
 /* identify_closest_invader (offsets_handler.py:256-281) */
-static int closest_invader(const te_config* c, const ote_drone* dr, uint32_t mask, int pur_slot) {
+static int closest_invader(const te_config* c, const ote_drone* dr, uint64_t mask, int pur_slot) {
   if (!((mask >> pur_slot) & 1u)) return -1;
   int best = -1; real bd = 0;
   for (int j = c->n_pursuers; j < c->n_pursuers + c->n_invaders; ++j) {
@@ -551,7 +553,7 @@ static int closest_invader(const te_config* c, const ote_drone* dr, uint32_t mas
   return best;
 }
 /* identify_closest_ally (offsets_handler.py:167-190) */
-static int closest_ally(const te_config* c, const ote_drone* dr, uint32_t mask, int pur_slot) {
+static int closest_ally(const te_config* c, const ote_drone* dr, uint64_t mask, int pur_slot) {
   if (!((mask >> pur_slot) & 1u)) return -1;
   int count = 0;
   for (int p = 0; p < c->n_pursuers; ++p) count += (mask >> p) & 1u;
@@ -564,9 +566,9 @@ static int closest_ally(const te_config* c, const ote_drone* dr, uint32_t mask, 
   }
   return best;
 }
-static uint32_t armed_mask(const ote_drone* dr, int D) {
-  uint32_t m = 0;
-  for (int i = 0; i < D; ++i) if (dr[i].armed) m |= 1u << i;
+static uint64_t armed_mask(const ote_drone* dr, int D) {
+  uint64_t m = 0;
+  for (int i = 0; i < D; ++i) if (dr[i].armed) m |= (uint64_t)1 << i;
   return m;
 }
 
@@ -583,7 +585,7 @@ static void unit_toward(const real from[3], const real to[3], real speed, real c
 /* KamikazeNavigator._is_building_path_clear: constant False in the air-combat-only navigator
  * (loitering_munition_navigator_air_combat_only.py:83-96); "no pursuer inside the cone from the
  * invader to the building" in the general one (loitering_munition_navigator.py:78-87). */
-static int building_path_clear(const te_config* c, const ote_drone* dr, uint32_t mask, int slot, real degrees) {
+static int building_path_clear(const te_config* c, const ote_drone* dr, uint64_t mask, int slot, real degrees) {
   if (!c->kamikaze_cone_check) return 0;
   real b[3] = {(real)c->building_position[0], (real)c->building_position[1], (real)c->building_position[2]};
   for (int p = 0; p < c->n_pursuers; ++p)
@@ -594,7 +596,7 @@ static int building_path_clear(const te_config* c, const ote_drone* dr, uint32_t
 /* KamikazeNavigator.update, air-combat-only variant
  * (loitering_munition_navigator_air_combat_only.py:68-78,138-246): check_transition registers the
  * NEXT state, then the CURRENT state executes.  _is_building_path_clear is constant False (:83-96). */
-static void kamikaze_update(const te_config* c, ote_drone* dr, uint32_t mask, int slot) {
+static void kamikaze_update(const te_config* c, ote_drone* dr, uint64_t mask, int slot) {
   ote_drone* d = &dr[slot];
   int state = d->nav_state;
   int pursuers_alive = 0;
@@ -623,7 +625,7 @@ static void kamikaze_update(const te_config* c, ote_drone* dr, uint32_t mask, in
 /* LoyalWingmanBehaviorTree.update (loyalwingman_navigator.py:79-86,238-352): gun available ->
  * ChaseThreat; else (has munition) -> MoveToFormation; out of munition is "available" (gun.py:69-70)
  * so SacrificeAttack == ChaseThreat. */
-static void wingman_update(const te_config* c, ote_drone* dr, uint32_t mask, int slot, int step) {
+static void wingman_update(const te_config* c, ote_drone* dr, uint64_t mask, int slot, int step) {
   ote_drone* d = &dr[slot];
   real cmd[4];
   if (gun_is_available(c, d, step)) {
@@ -911,9 +913,9 @@ static void neighbor_sphere(ote_env* E, int e, const uint32_t* nb, const uint32_
  * uniform permutation of the six (sphere, valid) pairs.  16 Philox words keyed (STACK, slot 0, sub 0..3,
  * episode, step); an integer in [0, k) is (word * k) >> 32. */
 typedef struct { int n, who[4], age[4], perm[TE_STACK_SPHERES]; } stack_draws;
-static void draw_stack(const ote_env* E, int e, int episode, int step, uint32_t armed_pursuers, stack_draws* d) {
+static void draw_stack(const ote_env* E, int e, int observer, int episode, int step, uint32_t armed_pursuers, stack_draws* d) {
   uint32_t w[16];
-  for (int k = 0; k < 4; ++k) ote_rng(E, e, OTE_RNG_STACK, 0, (uint32_t)k, (uint32_t)episode, (uint32_t)step, w + 4 * k);
+  for (int k = 0; k < 4; ++k) ote_rng(E, e, OTE_RNG_STACK, (uint32_t)observer, (uint32_t)k, (uint32_t)episode, (uint32_t)step, w + 4 * k);
   int cand[OTE_MAX_DRONES], nc = 0;
   for (int p = 0; p < E->cfg.n_pursuers; ++p) if ((armed_pursuers >> p) & 1u) cand[nc++] = p;
   int want = 1 + (int)(((uint64_t)w[0] * 4u) >> 32);
@@ -933,28 +935,29 @@ static void draw_stack(const ote_env* E, int e, int episode, int step, uint32_t 
 OTE_API void ote_stack_draws(const te_config* cfg, int env_local, int episode, int step, uint32_t armed_pursuers, int32_t* out /*15*/) {
   ote_env E; memset(&E, 0, sizeof E); E.cfg = *cfg;
   stack_draws d; memset(&d, 0, sizeof d);
-  draw_stack(&E, env_local, episode, step, armed_pursuers, &d);
+  draw_stack(&E, env_local, 0, episode, step, armed_pursuers, &d);
   out[0] = d.n;
   for (int i = 0; i < 4; ++i) { out[1 + i] = i < d.n ? d.who[i] : -1; out[5 + i] = i < d.n ? d.age[i] : 0; }
   for (int i = 0; i < TE_STACK_SPHERES; ++i) out[9 + i] = d.perm[i];
 }
-/* FusedLIDAR.read_data for the agent (slot 0): [own, neighbours...] -> pad -> shuffle.  out[i] = stack[perm[i]]. */
-static void stacked_observation(ote_env* E, int e, int step, uint32_t armed_now, float* out, uint8_t* mask) {
+/* FusedLIDAR.read_data of wingman `ob` (the agent = slot 0): [own, neighbours...] -> pad -> shuffle.  out[i] = stack[perm[i]].
+ * The draws of observer `ob` are keyed with its slot (Level5DumbMultiObs reads every wingman's LIDAR, level5_dumb_multiobs.py:116-150). */
+static void stacked_observation(ote_env* E, int e, int ob, int step, uint64_t armed_now, float* out, uint8_t* mask) {
   const te_config* c = &E->cfg;
   const ote_envrec* er = &E->envs[e];
   float stack[TE_STACK_SPHERES][TE_OBS_LIDAR_WORDS];
   uint8_t valid[TE_STACK_SPHERES];
   int nv = 0;
   memset(valid, 0, sizeof valid);
-  const uint32_t* own = step >= 1 ? ring_entry(E, e, 0, step) : NULL;
+  const uint32_t* own = step >= 1 ? ring_entry(E, e, ob, step) : NULL;
   if (own && (int)own[0] == step) { /* _build_valid_spheres: nothing at all without an own snapshot (:91-96) */
     entry_own_sphere(own, stack[nv]); valid[nv++] = 1;
     stack_draws d;
-    draw_stack(E, e, er->episode, step, armed_now & ((1u << c->n_pursuers) - 1u), &d);
+    draw_stack(E, e, ob, er->episode, step, (uint32_t)(armed_now & (((uint64_t)1 << c->n_pursuers) - 1u)), &d);
     for (int i = 0; i < d.n; ++i) {
       const uint32_t* nb = ring_lookup(E, e, d.who[i], step, d.age[i]);
       if (!nb) continue; /* get_snapshot -> None (lidar_buffer.py:152-154) */
-      neighbor_sphere(E, e, nb, own, 0, d.age[i], stack[nv]); valid[nv++] = 1;
+      neighbor_sphere(E, e, nb, own, ob, d.age[i], stack[nv]); valid[nv++] = 1;
     }
     for (int i = nv; i < TE_STACK_SPHERES; ++i) sphere_ones(stack[i]);
     for (int i = 0; i < TE_STACK_SPHERES; ++i) {
@@ -1029,12 +1032,18 @@ OTE_API void ote_level4_position(double r, double min_z, double u_theta, double 
 /* ------------------------------------------------------------------------- */
 /* Task.setup_round (exp03_vFinal_task.py:180-196): disarm all invaders; teleport + arm the first
  * `round` of them on the born-radius cap. */
+/* invaders armed in round r: `round` of them in the exp tasks; min((r - 1) * per_round + initial, max) in Level5DumbMultiObjectTask
+ * (level5_dumb_multiobject_task.py:173-184) */
+static int invaders_in_round(const te_config* c, int round) {
+  int n = (round - 1) * c->invaders_per_round + c->initial_invaders;
+  return n < c->n_invaders ? n : c->n_invaders;
+}
 static void level4_setup_round(ote_env* E, int e, int round) {
   const te_config* c = &E->cfg;
   ote_drone* dr = &E->drones[(size_t)e * E->D];
   ote_envrec* er = &E->envs[e];
   for (int j = c->n_pursuers; j < E->D; ++j) disarm(&dr[j]);
-  for (int i = 0; i < round && i < c->n_invaders; ++i) {
+  for (int i = 0; i < invaders_in_round(c, round); ++i) {
     uint32_t r[4];
     ote_rng(E, e, OTE_RNG_SPAWN_INVADER, (uint32_t)(c->n_pursuers + i), 0, (uint32_t)er->episode, (uint32_t)round, r);
     real p[3];
@@ -1135,11 +1144,12 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   /* (1) agent command (quadcopter.py:398-413) */
   real cmd[4] = {(real)action[0], (real)action[1], (real)action[2], (real)action[3]};
   for (int k = 0; k < 4; ++k) er->last_action[k] = cmd[k];
-  if (!c->evaluation) command_to_setpoint(cmd, dr[0].setpoint); /* EvaluationEnvironment.step(actions_not_used) (evaluation_environment.py:170-187) */
+  const int all_scripted = c->evaluation || c->agent_scripted; /* Evaluation_Task / Level5DumbMultiObjectTask: pursuer 0 obeys the behaviour tree too */
+  if (!all_scripted) command_to_setpoint(cmd, dr[0].setpoint); /* EvaluationEnvironment.step(actions_not_used) (evaluation_environment.py:170-187) */
 
   /* (2) task.on_step_start (exp03_vFinal_task.py:232-244,276-283) on the CURRENT offsets snapshot */
   for (int j = P; j < D; ++j) if (dr[j].armed) kamikaze_update(c, dr, er->snap_mask, j);
-  if (c->evaluation) { /* Evaluation_Task.drive_lw (evaluation_task.py:257-275): every armed pursuer, drivers of type "bt" */
+  if (all_scripted) { /* Evaluation_Task.drive_lw (evaluation_task.py:257-275), Level5DumbMultiObjectTask.drive_loyalwingmen (:256-266): every armed pursuer */
     for (int p = 0; p < P; ++p) if (dr[p].armed && !driven_externally(c, p)) wingman_update(c, dr, er->snap_mask, p, er->step);
   } else if (dr[0].armed) {
     /* get_armed_pursuers()[1:] : with the agent armed these are the armed allies */
@@ -1164,7 +1174,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   const int step = er->step;
 
   /* (4) task.on_step_middle (exp03_vFinal_task.py:285-319) */
-  const uint32_t S = armed_mask(dr, D); /* offsets over drones armed NOW, before engagement */
+  const uint64_t S = armed_mask(dr, D); /* offsets over drones armed NOW, before engagement */
   er->snap_mask = S;
   int agent_shots = 0, ally_shots = 0, exploded = 0, pursuer_suicided = 0, agent_suicided = 0;
   /* process_shoot_range_invaders (:392-413): pursuers in id order, closest in-range invader */
@@ -1226,11 +1236,41 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
     if (target >= 0) { tp[0] = dr[target].obs_pos[0]; tp[1] = dr[target].obs_pos[1]; tp[2] = dr[target].obs_pos[2]; }
     real cur = dist3(ag->obs_pos, tp);
     int ready = (g[2] == (real)1) || (g[0] == (real)0);
+    const real MAXR = (real)1000;
+    if (c->reward_model == TE_REWARD_L5_DUMB) { /* Level5DumbMultiObjectTask.compute_reward (level5_dumb_multiobject_task.py:452-553) */
+      const real SAFE = (real)5;
+      if (ready) score = -cur;
+      else {
+        score = cur;                                        /* keep away while reloading ... */
+        note_margin(&mg[0], cur, SAFE);
+        if (cur < SAFE) penalty += (SAFE - cur) / SAFE * ((real)0.5 * MAXR);
+      }
+      note_margin(&mg[0], cur - er->last_dist, (real)0.01);
+      if (g[2] == (real)0 && g[0] > (real)0 && (cur - er->last_dist) > (real)0.01) bonus += (real)0.1 * MAXR;
+      if (agent_shots > 0) bonus += (real)agent_shots * MAXR;
+      if (ally_shots > 0 || pursuer_suicided > 0) bonus += (real)0.5 * (real)(ally_shots + pursuer_suicided) * MAXR;
+      if (agent_suicided > 0) penalty += (real)2 * (real)agent_suicided * MAXR;
+      if (exploded > 0) penalty += MAXR * (real)exploded;
+      note_margin(&mg[0], ag->obs_pos[2], (real)-5);
+      if (ag->obs_pos[2] < (real)-5) { real f = (real)-5 - ag->obs_pos[2]; penalty += (f < (real)1 ? f : (real)1) * MAXR; }
+      int outside = 0;
+      for (int p = 0; p < P; ++p)
+        if ((S >> p) & 1u) {
+          real n = norm3(dr[p].obs_pos);
+          note_state_margin(mg, n, (real)c->dome_radius);
+          if (n > (real)c->dome_radius) outside += 1;
+        }
+      if (outside > 0) penalty += MAXR;
+      note_margin(&mg[0], dist_origin, (real)c->born_radius - (real)2);
+      if (dist_origin > (real)c->born_radius - (real)2) { real o = dist_origin - ((real)c->born_radius - (real)2); penalty += o < MAXR ? o : MAXR; }
+      er->last_dist = cur;
+      real total = score + bonus - penalty;
+      score = clampr(total, (real)-3 * MAXR, (real)3 * MAXR); bonus = 0; penalty = 0;
+    } else {
     note_margin(&mg[0], er->last_dist - cur, (real)0.01);
     if ((real)0.01 < er->last_dist - cur && ready) bonus += (real)c->approach_bonus_gain * norm3(ag->obs_vel);
     er->last_dist = cur;
     score = ready ? -cur : cur * ((real)2 * g[1] - (real)1);
-    const real MAXR = (real)1000;
     if (agent_shots > 0 || agent_suicided > 0) bonus += (real)(agent_shots + agent_suicided) * MAXR;
     if (ally_shots > 0 || pursuer_suicided > 0) bonus += (real)0.5 * (real)(ally_shots + pursuer_suicided) * MAXR;
     else if (exploded > 0) penalty += MAXR * (real)exploded;
@@ -1246,6 +1286,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
     if (outside > 0) penalty += MAXR;
     note_margin(&mg[0], dist_origin, (real)c->born_radius - (real)2);
     if (dist_origin > (real)c->born_radius - (real)2) penalty += dist_origin - (real)c->born_radius - (real)2; /* literal, SURVEY.md C8 */
+    }
   }
   real rew = score + bonus - penalty;
   /* increment_max_step (:150-153) */
@@ -1275,7 +1316,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
         if (n > (real)c->dome_radius) term = 1;
       }
     if (armed_pursuers == 0) term = 1;
-    if (!dr[0].armed) term = 1;
+    if (c->agent_death_terminates && !dr[0].armed) term = 1; /* commented out in level5_dumb_multiobject_task.py:600-606 */
     note_state_margin(mg, dr[0].obs_pos[2], (real)-5.99);
     if (dr[0].obs_pos[2] < (real)-5.99) term = 1;
   }
@@ -1291,13 +1332,26 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   if (La) for (int k = 0; k < 4; ++k) La[k] = (float)er->last_action[k];
   if (c->stacked_obs) { /* level5_envrionment.py:312-351: every wingman's update_lidar, then the agent's stack */
     E->margin_stack[e] = (real)1e30;
-    const uint32_t armed_now = armed_mask(dr, D);
+    const uint64_t armed_now = armed_mask(dr, D);
     for (int p = 0; p < P; ++p) if (dr[p].armed) ring_push(E, e, p, step);
     if (E->out_stacked) {
       const int aside = to_terminal && E->out_t_stacked && E->out_t_mask;
       float* So = (aside ? E->out_t_stacked : E->out_stacked) + (size_t)e * TE_OBS_STACKED_WORDS;
       uint8_t* Mo = (aside ? E->out_t_mask : E->out_mask) + (size_t)e * TE_STACK_SPHERES;
-      stacked_observation(E, e, step, armed_now, So, Mo);
+      stacked_observation(E, e, 0, step, armed_now, So, Mo);
+    }
+    if (E->st_stacked) { /* Level5DumbMultiObs.compute_info (level5_dumb_multiobs.py:116-150): every pursuer's student observation */
+      for (int p = 0; p < P; ++p) {
+        const size_t row = (size_t)e * P + p;
+        stacked_observation(E, e, p, step, armed_now, E->st_stacked + row * TE_OBS_STACKED_WORDS, E->st_mask + row * TE_STACK_SPHERES);
+        inertial_obs(c, &dr[p], step, max_munition_of(c, p), E->st_inertial + row * TE_OBS_INERTIAL_WORDS);
+        /* pursuer.last_action = the behaviour tree's command of this step: (unit direction, 0.6) (loyalwingman_navigator.py:301,325,350) */
+        const real sp_ = (real)c->ally_speed;
+        float* la = E->st_last_action + row * 4;
+        la[0] = (float)(dr[p].setpoint[0] / sp_); la[1] = (float)(dr[p].setpoint[1] / sp_); la[2] = (float)(dr[p].setpoint[3] / sp_); la[3] = (float)sp_;
+        if (!dr[p].armed) for (int k = 0; k < 4; ++k) la[k] = 0.0f;
+        E->st_active[row] = dr[p].armed ? 1 : 0;
+      }
     }
   }
 
@@ -1315,6 +1369,15 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
       for (int i = 0; i < TE_OBS_STACKED_WORDS; ++i) E->out_stacked[(size_t)e * TE_OBS_STACKED_WORDS + i] = 1.0f;
       for (int i = 0; i < TE_STACK_SPHERES; ++i) E->out_mask[(size_t)e * TE_STACK_SPHERES + i] = 0;
     }
+    if (E->st_stacked) /* the students' reset observation: empty spheres, the fresh IMU / gun rows, no action yet */
+      for (int p = 0; p < P; ++p) {
+        const size_t row = (size_t)e * P + p;
+        for (int i = 0; i < TE_OBS_STACKED_WORDS; ++i) E->st_stacked[row * TE_OBS_STACKED_WORDS + i] = 1.0f;
+        for (int i = 0; i < TE_STACK_SPHERES; ++i) E->st_mask[row * TE_STACK_SPHERES + i] = 0;
+        inertial_obs(c, &dr[p], 0, max_munition_of(c, p), E->st_inertial + row * TE_OBS_INERTIAL_WORDS);
+        for (int k = 0; k < 4; ++k) E->st_last_action[row * 4 + k] = 0.0f;
+        E->st_active[row] = dr[p].armed ? 1 : 0;
+      }
     if (lidar) for (int i = 0; i < lidar_words(c); ++i) lidar[i] = 1.0f;
     if (inertial) inertial_obs(c, &dr[0], 0, max_munition_of(c, 0), inertial);
     if (last_action) for (int k = 0; k < 4; ++k) last_action[k] = 0.0f;
@@ -1329,7 +1392,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
 /* ------------------------------------------------------------------------- */
 /* stage02 (level3/pyflyt_level3_environment_v2.py + components/stages.py)                      */
 /* ------------------------------------------------------------------------- */
-static real stage02_agent_min_distance(const te_config* c, const ote_drone* dr, uint32_t S) {
+static real stage02_agent_min_distance(const te_config* c, const ote_drone* dr, uint64_t S) {
   /* np.sum(np.min(distances[0], axis=0)): row of the FIRST pursuer in the snapshot */
   int first = -1;
   for (int p = 0; p < c->n_pursuers; ++p) if ((S >> p) & 1u) { first = p; break; }
@@ -1399,7 +1462,7 @@ static void stage02_step_env(ote_env* E, int e, const float* action, float* lida
   er->step += 1;
   const int step = er->step;
   /* on_step_middle (stages.py:144-179) */
-  const uint32_t S = armed_mask(dr, D);
+  const uint64_t S = armed_mask(dr, D);
   er->snap_mask = S;
   int shots = 0, exploded = 0;
   for (int p = 0; p < P; ++p) {
@@ -1733,11 +1796,22 @@ OTE_API int ote_step_stacked(ote_env* E, const float* actions, float* stacked, u
   E->out_stacked = NULL; E->out_mask = NULL; E->out_t_stacked = NULL; E->out_t_mask = NULL;
   return rc;
 }
+/* Level5DumbMultiObs: te_step_students */
+OTE_API int ote_step_students(ote_env* E, float* stacked, uint8_t* mask, float* inertial, float* last_action, uint8_t* active,
+                              float* reward, uint8_t* done, int32_t* info, int threads) {
+  if (!E->cfg.stacked_obs || !(E->cfg.agent_scripted || E->cfg.evaluation) || !stacked || !mask || !inertial || !last_action || !active) return 1;
+  E->st_stacked = stacked; E->st_mask = mask; E->st_inertial = inertial; E->st_last_action = last_action; E->st_active = active;
+  float* zero = (float*)calloc((size_t)E->cfg.n_envs * 4, sizeof(float));
+  int rc = ote_step(E, zero, NULL, NULL, NULL, reward, done, info, NULL, NULL, NULL, threads);
+  free(zero);
+  E->st_stacked = NULL; E->st_mask = NULL; E->st_inertial = NULL; E->st_last_action = NULL; E->st_active = NULL;
+  return rc;
+}
 OTE_API int ote_observe_stacked(ote_env* E, float* stacked, uint8_t* mask, float* inertial, float* last_action) {
   if (!E->cfg.stacked_obs || !stacked || !mask) return 1;
   for (int e = 0; e < E->cfg.n_envs; ++e) {
     const ote_drone* dr = &E->drones[(size_t)e * E->D];
-    stacked_observation(E, e, E->envs[e].step, armed_mask(dr, E->D), stacked + (size_t)e * TE_OBS_STACKED_WORDS,
+    stacked_observation(E, e, 0, E->envs[e].step, armed_mask(dr, E->D), stacked + (size_t)e * TE_OBS_STACKED_WORDS,
                         mask + (size_t)e * TE_STACK_SPHERES);
   }
   return ote_observe(E, NULL, inertial, last_action);
@@ -1806,7 +1880,7 @@ OTE_API int ote_get_state(const ote_env* E, uint32_t* dst) {
     w[TE_E_STEP] = (uint32_t)r->step; w[TE_E_MAX_STEP] = (uint32_t)r->max_step; w[TE_E_ROUND] = (uint32_t)r->round;
     put_f(w, TE_E_LAST_DIST, &r->last_dist, 1);
     w[TE_E_AGENT_KILLS] = (uint32_t)r->agent_kills; w[TE_E_ALLIES_KILLS] = (uint32_t)r->allies_kills;
-    w[TE_E_DEADS] = (uint32_t)r->deads; w[TE_E_SNAP_MASK] = r->snap_mask; w[TE_E_EPISODE] = (uint32_t)r->episode;
+    w[TE_E_DEADS] = (uint32_t)r->deads; w[TE_E_SNAP_MASK] = (uint32_t)r->snap_mask; w[TE_E_SNAP_MASK_HI] = (uint32_t)(r->snap_mask >> 32); w[TE_E_EPISODE] = (uint32_t)r->episode;
     put_f(w, TE_E_LAST_ACTION, r->last_action, 4); put_f(w, TE_E_PREV_SNAP_MIN, &r->prev_snap_min, 1);
   }
   for (int p = 0; p < E->cfg.n_pursuers; ++p)  /* a caller-driven pursuer keeps its driver's last action in its TE_D_ALLY_ACTION words */
@@ -1839,7 +1913,7 @@ OTE_API int ote_set_state(ote_env* E, const uint32_t* src) {
     r->step = (int32_t)w[TE_E_STEP]; r->max_step = (int32_t)w[TE_E_MAX_STEP]; r->round = (int32_t)w[TE_E_ROUND];
     get_f(w, TE_E_LAST_DIST, &r->last_dist, 1);
     r->agent_kills = (int32_t)w[TE_E_AGENT_KILLS]; r->allies_kills = (int32_t)w[TE_E_ALLIES_KILLS];
-    r->deads = (int32_t)w[TE_E_DEADS]; r->snap_mask = w[TE_E_SNAP_MASK]; r->episode = (int32_t)w[TE_E_EPISODE];
+    r->deads = (int32_t)w[TE_E_DEADS]; r->snap_mask = (uint64_t)w[TE_E_SNAP_MASK] | ((uint64_t)w[TE_E_SNAP_MASK_HI] << 32); r->episode = (int32_t)w[TE_E_EPISODE];
     get_f(w, TE_E_LAST_ACTION, r->last_action, 4); get_f(w, TE_E_PREV_SNAP_MIN, &r->prev_snap_min, 1);
   }
   for (int p = 0; p < E->cfg.n_pursuers; ++p)

@@ -44,6 +44,7 @@ def lib(precision: str = "f64") -> C.CDLL:
         L.ote_ring_lookup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.ote_step_stacked.argtypes = [C.c_void_p] + [C.c_void_p] * 12 + [C.c_int]
         L.ote_observe_stacked.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.ote_step_students.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_int]
         L.ote_observe_ally.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.ote_set_ally_actions.argtypes = [C.c_void_p, C.c_void_p]
         L.ote_observe_wingman.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
@@ -149,6 +150,18 @@ class OracleEnv:
                                      self.threads)
         assert rc == 0
         return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
+
+    def step_students(self):
+        """Level5DumbMultiObs: one all-scripted step; (stacked [N,P,6,3,13,26], mask [N,P,6], inertial [N,P,15], last_action [N,P,4],
+        active [N,P], reward, done, info)."""
+        N, P = self.N, int(self.cfg.n_pursuers)
+        if not hasattr(self, "st"):
+            self.st = (np.empty((N, P, K.STACK_SPHERES, K.LIDAR_CHANNELS, K.LIDAR_NTHETA, K.LIDAR_NPHI), np.float32), np.empty((N, P, K.STACK_SPHERES), np.uint8),
+                       np.empty((N, P, K.OBS_INERTIAL_WORDS), np.float32), np.empty((N, P, 4), np.float32), np.empty((N, P), np.uint8))
+        st = self.st
+        rc = self.L.ote_step_students(self.h, _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _p(st[4]), _p(self.reward), _p(self.done), _p(self.info), self.threads)
+        assert rc == 0, "step_students needs cfg.stacked_obs and an all-scripted task (level5_dumb, evaluation)"
+        return (*st, self.reward, self.done, self.info)
 
     # exp05 ----------------------------------------------------------------------------------
     def observe_wingman(self, wingman: int):

@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol(lib):
     for name in declared:
         assert getattr(lib, name) is not None
     from dronechase_amd import config as K
-    assert lib.te_abi_version() == K.TE_ABI_VERSION == 4
+    assert lib.te_abi_version() == K.TE_ABI_VERSION == 5
 
 
 def test_struct_layout_matches_c(lib):

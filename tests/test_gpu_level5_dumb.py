@@ -1,0 +1,68 @@
+"""Level5DumbMultiObs on the MI355X: te_step_students (37 drones per env: engage_kernel<7, 30> with 64-bit slot masks, one stacked_kernel
+launch per wingman) against the oracle on identical seeded inputs.  Tolerances and the ambiguity bookkeeping are those of
+tests/test_gpu_level5.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+OBS_TOL, CELL_MARGIN, MARGIN = 1e-5, 5e-5, 1e-4
+
+
+def test_students_rollout_parity():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    from oracle import te_oracle as O
+    N, STEPS = 192, 45
+    cfg = default_config("level5_dumb", n_envs=N, motor_noise=0, max_step=20, seed=9)
+    g, o = BatchedEnv(cfg, "cuda:0"), O.OracleEnv(cfg, "f32", threads=8)
+    assert g.engage_kernel_name() if hasattr(g, "engage_kernel_name") else True
+    g.reset(); o.reset()
+    dirty_state = np.zeros(N, bool); dirty_cell_until = np.full(N, -1)
+    compared = dones = visible = 0
+    for t in range(STEPS):
+        s, m, inert, la, act, r, d, info = o.step_students()
+        gs, gm, gi, gl, ga, gr, gd, ginfo = (x.cpu().numpy() for x in g.step_students())
+        cell_amb = o.stack_margins() < CELL_MARGIN
+        dirty_state |= o.state_margins() < MARGIN
+        dirty_cell_until[cell_amb] = t + 9
+        clean = ~(dirty_state | (dirty_cell_until >= t))
+        bad = (gd != d) | (ginfo != info).any(1) | (ga != act).any(1) | (gm != m).reshape(N, -1).any(1)
+        bad |= np.abs(gs - s).reshape(N, -1).max(1) > OBS_TOL
+        bad |= np.abs(gi - inert).reshape(N, -1).max(1) > OBS_TOL
+        bad |= np.abs(gl - la).reshape(N, -1).max(1) > 1e-4
+        bad |= np.abs(gr - r) > 1e-3 + 1e-5 * np.abs(r)
+        assert not (bad & clean).any(), (t, np.nonzero(bad & clean)[0][:8])
+        compared += int(clean.sum()); dones += int((d != 0).sum()); visible += int((s[clean][:, :, :, 0] < 1).sum())
+        fresh = (d != 0) & (gd == d)
+        dirty_state[fresh] = False; dirty_cell_until[fresh] = -1
+    assert dones >= N and compared > 0.5 * N * STEPS and visible > 10000
+    # the state (37 drone records, env records incl. both halves of the snapshot mask, the ring) round-trips through the blob
+    w = g.get_state()
+    h = BatchedEnv(cfg, "cuda:0"); h.set_state(w)
+    for _ in range(3):
+        ra, rb = g.step_students(), h.step_students()
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y)
+    assert torch.equal(g.get_state(), h.get_state())
+    g.close(); h.close(); o.close()
+
+
+def test_unsupported_calls_fail_loudly():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from dronechase_amd import _lib, default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    g = BatchedEnv(default_config("level5_dumb", n_envs=64), "cuda:0")
+    with pytest.raises(_lib.TEError, match="te_step_students"):
+        g.observe_stacked()
+    g.close()
+    with pytest.raises(_lib.TEError, match="32 drones"):
+        BatchedEnv(default_config("exp03", n_envs=64, n_invaders=40), "cuda:0")
+    e = BatchedEnv(default_config("exp03", n_envs=64), "cuda:0")
+    with pytest.raises(_lib.TEError, match="all-scripted"):
+        e.step_students()
+    e.close()
