@@ -18,7 +18,6 @@ def test_students_rollout_parity():
     N, STEPS = 192, 45
     cfg = default_config("level5_dumb", n_envs=N, motor_noise=0, max_step=20, seed=9)
     g, o = BatchedEnv(cfg, "cuda:0"), O.OracleEnv(cfg, "f32", threads=8)
-    assert g.engage_kernel_name() if hasattr(g, "engage_kernel_name") else True
     g.reset(); o.reset()
     dirty_state = np.zeros(N, bool); dirty_cell_until = np.full(N, -1)
     compared = dones = visible = 0
