@@ -158,5 +158,30 @@ class Level5Environment(_SingleEnv):  # threatsense/level5/level5_envrionment.py
     TASK = "level5"
 
 
-ENV_TASKS = {cls: cls.TASK for cls in (Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment, EvaluationEnvironment,
+class Level5DumbMultiObs(_SingleEnv):  # threatsense/level5/level5_dumb_multiobs.py:10
+    """The imitation-data collector's environment (apps/threatsense_runner/collect_and_save.py): seven wingmen, all flown by the behaviour
+    tree, 5 -> 30 invaders.  As in the reference the observation is a dummy `zeros(1)`, `step` ignores its action, and everything of
+    interest travels in `info`: `student_observations` = the stacked observation (stacked_spheres [6,3,13,26], validity_mask [6],
+    inertial_data [15], last_action [4]) of every ARMED wingman, `teacher_actions` = their behaviour-tree commands (:116-150).  The batched
+    form is `BatchedEnv(default_config("level5_dumb", ...)).step_students()` -> [N,7,...] tensors on the device + the `active` mask."""
+    TASK = "level5_dumb"
+
+    def __init__(self, GUI: bool = False, rl_frequency: int = 15, dome_radius: Optional[float] = None, **overrides):
+        super().__init__(dome_radius, rl_frequency, GUI, **overrides)
+        from . import spaces as S
+        self.observation_space = S.Box(0, 1, shape=(1,), dtype=np.float32)      # level5_dumb_multiobs.py:27-33
+
+    def reset(self, seed=0, options=None):
+        self._b.reset()
+        return np.zeros(1, np.float32), {"student_observations": [], "teacher_actions": []}
+
+    def step(self, action=None):
+        stacked, mask, inertial, last_action, active, reward, done, _info = (t[0].cpu().numpy() if t.dim() > 1 else t.cpu().numpy() for t in self._b.step_students())
+        rows = [p for p in range(stacked.shape[0]) if active[p]]
+        students = [{"stacked_spheres": stacked[p], "validity_mask": mask[p].astype(bool), "inertial_data": inertial[p], "last_action": last_action[p]} for p in rows]
+        info = {"student_observations": students, "teacher_actions": [last_action[p] for p in rows]}
+        return np.zeros(1, np.float32), float(reward[0]), bool(done[0]), False, info
+
+
+ENV_TASKS = {cls: cls.TASK for cls in (Level5DumbMultiObs, Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment, EvaluationEnvironment,
                                        PyflytL2EnviromentModifiedV2, PyflytL3EnviromentV2, Level5Environment)}

@@ -67,3 +67,25 @@ def test_unsupported_calls_fail_loudly():
     with pytest.raises(_lib.TEError, match="all-scripted"):
         e.step_students()
     e.close()
+
+
+def test_reference_named_environment():
+    """Level5DumbMultiObs(GUI, rl_frequency) as the collector uses it (apps/threatsense_runner/collect_and_save.py:140-170): dummy
+    observation, everything in info."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from dronechase_amd.envs import Level5DumbMultiObs
+    env = Level5DumbMultiObs(GUI=False, rl_frequency=15)
+    obs, info = env.reset()
+    assert obs.shape == (1,) and info["student_observations"] == []
+    seen = 0
+    for _ in range(12):
+        obs, reward, terminated, truncated, info = env.step(np.zeros(4))
+        assert obs.shape == (1,) and truncated is False and len(info["student_observations"]) == len(info["teacher_actions"]) == 7
+        for so, ta in zip(info["student_observations"], info["teacher_actions"]):
+            assert so["stacked_spheres"].shape == (6, 3, 13, 26) and so["validity_mask"].shape == (6,) and so["inertial_data"].shape == (15,)
+            assert abs(ta[3] - 0.6) < 1e-6 and abs(np.linalg.norm(ta[:3]) - 1) < 1e-4 and np.array_equal(so["last_action"], ta)
+            seen += int(so["validity_mask"].sum())
+    assert seen > 20
+    env.close()
