@@ -64,6 +64,9 @@ struct Params {
   unsigned long long* dbg;  // phase stamps of one block (diagnostic builds with -DTE_DEBUG_STAMPS only; else unused)
 };
 #ifdef TE_DEBUG_STAMPS
+__device__ unsigned long long* g_te_dbg = nullptr;
+#endif
+#if defined(TE_DEBUG_STAMPS) && !defined(TE_NO_STAMP)
 #define TE_STAMP(p, blk, idx)                                                                     \
   do {                                                                                            \
     if ((p).dbg && threadIdx.x == 0) {                                                            \
@@ -72,14 +75,16 @@ struct Params {
       (p).dbg[64 + blockIdx.x * 16 + (idx)] = t_; /* every block: tools/k2_blocks.py */            \
     }                                                                                             \
   } while (0)
+#else
+#define TE_STAMP(p, blk, idx) do {} while (0)
+#endif
 // finer stamps from inside the per-env logic (lane 0 of wave 0 of every block), slots 8..15 of the block's record
-__device__ unsigned long long* g_te_dbg = nullptr;
+#if defined(TE_DEBUG_STAMPS) && !defined(TE_NO_LSTAMP)
 #define TE_LSTAMP(idx)                                                                            \
   do {                                                                                            \
     if (g_te_dbg && threadIdx.x == 0) g_te_dbg[64 + blockIdx.x * 16 + (idx)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
-#define TE_STAMP(p, blk, idx) do {} while (0)
 #define TE_LSTAMP(idx) do {} while (0)
 #endif
 

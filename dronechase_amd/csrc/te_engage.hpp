@@ -32,7 +32,7 @@
 
 namespace te {
 
-#ifdef TE_DEBUG_STAMPS
+#if defined(TE_DEBUG_STAMPS) && !defined(TE_NO_ESTAMP)
 // phase stamps of every workgroup (diagnostic builds only; tools/engage_stamps.py): idx 0..15 of the block's record
 #define TE_ESTAMP(idx, wait)                                                                                   \
   do {                                                                                                         \
@@ -570,7 +570,10 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   TE_ESTAMP(7, 0);
   // ---- the observation of the state the step leaves (post-reset values for an auto-reset env)
   if (o.obs.inertial) {
-    inertial_row(rows + lane * TE_OBS_INERTIAL_WORDS, px[0], py[0], pz[0], ag, mun[0], lf[0], step);   // stride 15: conflict-free
+    float row15[TE_OBS_INERTIAL_WORDS];
+    inertial_row(row15, px[0], py[0], pz[0], ag, mun[0], lf[0], step);
+#pragma unroll
+    for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) rows[lane * TE_OBS_INERTIAL_WORDS + k] = row15[k];   // stride 15: conflict-free
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int n_out = min(64, p.N - (int)blockIdx.x * 64) * TE_OBS_INERTIAL_WORDS;
     float* dst = o.obs.inertial + (size_t)blockIdx.x * 64 * TE_OBS_INERTIAL_WORDS;
@@ -692,7 +695,7 @@ TE_DEV void inertial_row_regs(const te_config& c, float* dst, float x, float y, 
   dst[12] = gs[0]; dst[13] = gs[1]; dst[14] = gs[2];
 }
 // the chunk's [64, 15] rows through LDS: 15 contiguous 256-byte stores; last_action straight from the lane
-TE_DEV void write_rows_regs(const Params& p, const ObsOut& o, float* rows, int lane, bool valid, int env, const float row[TE_OBS_INERTIAL_WORDS], float4 act) {
+TE_DEV void write_rows_regs(const Params& p, const ObsOut& o, float (&rows)[64 * TE_OBS_INERTIAL_WORDS], int lane, bool valid, int env, const float row[TE_OBS_INERTIAL_WORDS], float4 act) {
   if (o.inertial) {
 #pragma unroll
     for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) rows[lane * TE_OBS_INERTIAL_WORDS + k] = row[k];

@@ -58,8 +58,9 @@ namespace te {
 // the background is written once and not read by this launch: non-temporal ("nt") stores keep it from displacing the
 // drone state in L2 (measured 58.7 -> 56.1 us per launch)
 typedef float te_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t te_u4 __attribute__((ext_vector_type(4)));
 #define TE_FILL_STORE(ptr) __builtin_nontemporal_store((te_f4){1.0f, 1.0f, 1.0f, 1.0f}, reinterpret_cast<te_f4*>(ptr))
-struct FillJob { float* lidar; uint32_t total_quads; uint32_t n_fill_waves; };
+struct FillJob { float* lidar; uint32_t total_quads; uint32_t n_fill_waves; uint32_t mode; };
 
 // what kamikaze_update() reads of the other drones, through the wave's buffer resource
 struct NavView {
@@ -236,8 +237,29 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
   }
 }
 
+// Diagnostic builds (-DTE_DEBUG_STAMPS): every workgroup of the sub-step kernel leaves {start, end, HW_ID | XCC_ID << 32, kind} behind the
+// engage kernel's records (tools/k1_waves.py: which SIMD flew how many waves, and when each finished).  kind: 0 idle candidate, 1 fill, 2 dense, 3 mixed
+#ifdef TE_DEBUG_STAMPS
+#define TE_K1_BASE(p) (64 + 16 * (size_t)((p).Npad / kEPB + 1))
+#define TE_K1_BEGIN const unsigned long long k1_t0_ = __builtin_amdgcn_s_memrealtime();
+#define TE_K1_END(kind)                                                                                               \
+  do {                                                                                                                \
+    if (p.dbg && threadIdx.x == 0) {                                                                                  \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
+      unsigned long long* r_ = p.dbg + TE_K1_BASE(p) + 4 * (size_t)blockIdx.x;                                        \
+      r_[0] = k1_t0_; r_[1] = __builtin_amdgcn_s_memrealtime();                                                       \
+      r_[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+      r_[3] = (kind);                                                                                                 \
+    }                                                                                                                 \
+  } while (0)
+#else
+#define TE_K1_BEGIN
+#define TE_K1_END(kind) do {} while (0)
+#endif
+
 template <int FAMILY, bool NOISE, bool FILL, bool CES = true>
 __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params p, const float* __restrict__ actions, FillJob fill) {
+  TE_K1_BEGIN
   int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (unsigned)TE_K1_BLOCK + threadIdx.x) >> 6));
   const int lane = threadIdx.x & 63;
   const int D = p.D;
@@ -247,8 +269,25 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
     if (wave < (int)fill.n_fill_waves) {  // ---- fill wave
       // grid-stride: at any moment the fill waves write one contiguous n_fill_waves KB window, which the address
       // interleave spreads over every HBM channel
+      if (fill.mode >= 1) {
+        // Scalar loop: one buffer store per 1 KB block, the block offset in an SGPR.  The pointer form below costs three VALU
+        // instructions per store (64-bit address, index, compare), and next to five or six flights on the same SIMD every one of them
+        // queues behind the flights' VALU work: the background then finishes 10-20 us after the last flight (tools/k1_waves.py).
+        if (fill.mode >= 2) __builtin_amdgcn_s_setprio(3);
+        const uint32_t n_blocks = fill.total_quads >> 6;   // whole 1 KB blocks
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(fill.lidar, 0, (int)(n_blocks << 10), 0x00020000);
+        const int voff = lane * 16;
+        const te_u4 ones = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
+        for (uint32_t b = (uint32_t)wave; b < n_blocks; b += fill.n_fill_waves)
+          __builtin_amdgcn_raw_buffer_store_b128(ones, rs, voff, (int)(b << 10), 2 /* nt */);
+        const uint32_t q = (n_blocks << 6) + (uint32_t)lane;   // the last partial block
+        if ((uint32_t)wave == n_blocks % fill.n_fill_waves && q < fill.total_quads) TE_FILL_STORE(fill_dst + q);
+        TE_K1_END(1);
+        return;
+      }
       const uint32_t stride = fill.n_fill_waves * 64u;
       for (uint32_t q = (uint32_t)wave * 64u + (uint32_t)lane; q < fill.total_quads; q += stride) TE_FILL_STORE(fill_dst + q);
+      TE_K1_END(1);
       return;
     }
     wave -= (int)fill.n_fill_waves;
@@ -262,24 +301,26 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
     wave -= n_head;
     const int m = wave / nchunks, chunk = wave - m * nchunks;
     const int count = __builtin_amdgcn_readfirstlane((int)((const uint32_t* __restrict__)p.mixed_count)[chunk]);
-    if (m * 64 >= count) return;
+    if (m * 64 >= count) { TE_K1_END(0); return; }
     const int i = m * 64 + lane;
     const bool valid = i < count;
     const uint32_t item = valid ? (uint32_t)p.mixed_items[(size_t)chunk * kMixedCap + i] : 0u;
     fly<FAMILY, NOISE, true, CES>(p, actions, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid);
+    TE_K1_END(3);
     return;
   }
   if (wave >= n_head) wave -= n_mixed;
   const int slot = wave / nchunks;
   const int chunk = wave - slot * nchunks;
-  if (slot >= D) return;
+  if (slot >= D) { TE_K1_END(0); return; }
   // Does this (slot, chunk) fly as a dense wave?  One wave-uniform SCALAR load: the ~8 000 idle waves of a launch used
   // to wait for a vector flag load (and issue a background store) behind the fill waves' stores: +15 us per launch.
   const uint32_t* __restrict__ sm32 = reinterpret_cast<const uint32_t*>(p.slot_mask);
   const uint32_t chunk_mask = __builtin_amdgcn_readfirstlane(sm32[2 * chunk + (slot >> 5)]);   // the 32-bit half that holds this slot's bit
-  if (!((chunk_mask >> (slot & 31)) & 1u)) return;
+  if (!((chunk_mask >> (slot & 31)) & 1u)) { TE_K1_END(0); return; }
   const int env = chunk * 64 + lane;  // planes are padded to Npad: lanes beyond N still read in bounds
   fly<FAMILY, NOISE, false, CES>(p, actions, slot, env, env < p.N);
+  TE_K1_END(2);
 }
 
 // ============================================================================================
@@ -767,6 +808,7 @@ struct te_env {
   int family;
   size_t lds_bytes;
   size_t stack_lds_bytes = 0;  // stacked_kernel (level5)
+  size_t dbg_words = 0;       // diagnostic builds: length of p.dbg
   int engage_regs = 0;         // 1 = engage_kernel<2, 9>, 2 = engage_kernel<6, 12> (level4 family), 3 = engage_stage02_kernel<2, 8>, 4 = engage_stage01_kernel (te_engage.hpp: the env in registers, one wave per
                                // chunk); 0 = engage_observe_kernel (LDS phases): other shapes, stage01 / stage02, TE_ENGAGE=lds
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
@@ -780,6 +822,7 @@ struct te_env {
     float *t_lidar = nullptr, *t_inertial = nullptr, *t_last_action = nullptr;
     uint8_t *done = nullptr, *mask = nullptr; int32_t* info = nullptr; uint32_t* blob = nullptr;
   } hs;
+  int fill_mode = 1;       // TE_FILL_MODE: 0 pointer loop, 1 scalar buffer loop, 2 + s_setprio 3
   int n_fill_waves = 256;  // fill waves of the sub-step kernel: one per CU of an MI355X; four per CU for the six-sphere background of
                            // level5, where ~9 flight waves per SIMD would leave one fill wave too small a share of the issue slots
                            // (605 -> 567 us/step; 512 / 1024 fill waves cost stage03 7 / 40 %); TE_FILL_WAVES overrides
@@ -905,6 +948,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   e->p.dense_min = kDenseMin;
   if (const char* v = getenv("TE_DENSE_MIN")) { int n = atoi(v); if (n >= 1 && n <= 65) e->p.dense_min = n; }
   if (cfg->stacked_obs) e->n_fill_waves = 1024;
+  if (const char* v = getenv("TE_FILL_MODE")) e->fill_mode = atoi(v);
   if (const char* v = getenv("TE_FILL_WAVES")) { int n = atoi(v); if (n >= 1 && n <= (1 << 20)) e->n_fill_waves = n; }
   {
     hipError_t le = hipSuccess;
@@ -971,7 +1015,8 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     TE_HIP_OR_BAIL(hipMemsetAsync(e->p.ring, 0, ring_bytes, nullptr));
   }
 #ifdef TE_DEBUG_STAMPS
-  const size_t dbg_words = 64 + 16 * (size_t)(e->p.Npad / kEPB + 1);
+  const size_t dbg_words = 64 + 16 * (size_t)(e->p.Npad / kEPB + 1) + 4 * ((size_t)(e->p.D + kMixedWaves) * (e->p.Npad >> 6) + 4096);  // engage records, then the sub-step kernel's
+  e->dbg_words = dbg_words;
   if (hipMalloc(&e->p.dbg, dbg_words * sizeof(unsigned long long)) != hipSuccess) e->p.dbg = nullptr;
   else { (void)hipMemset(e->p.dbg, 0, dbg_words * sizeof(unsigned long long)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_te_dbg), &e->p.dbg, sizeof(e->p.dbg)); }
 #endif
@@ -1143,12 +1188,12 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   const bool noise = p.cfg.motor_noise != 0;
   // LIDAR background: N*1014 floats = quads float4 (+ <4 tail floats).  The drone waves write one float4 per
   // lane; the rest is split evenly over the fill waves.
-  FillJob fill{nullptr, 0u, 0u};
+  FillJob fill{nullptr, 0u, 0u, 0u};
   const size_t n_floats = (size_t)p.N * lidar_words_per_env;
   if (obs_lidar) {
     const size_t quads = n_floats >> 2;
     if (quads >= 4096 && quads < (1ull << 32)) {
-      fill = FillJob{obs_lidar, (uint32_t)quads, (uint32_t)e->n_fill_waves};
+      fill = FillJob{obs_lidar, (uint32_t)quads, (uint32_t)e->n_fill_waves, (quads >> 6) < (1u << 22) ? (uint32_t)e->fill_mode : 0u};  // the SGPR block offset is 32-bit: < 4 GB
       if (n_floats & 3) hipLaunchKernelGGL(fill_ones_kernel, dim3(1), dim3(64), 0, st, obs_lidar + (quads << 2), n_floats & 3);
     } else {  // tiny or huge buffers: plain fill kernel first
       hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, obs_lidar, n_floats);
@@ -1174,9 +1219,11 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
             ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}};
   const bool contact = p.cfg.drone_contact != 0;   // its own instantiations: the contact pass would cost every launch ~150 VGPRs
   if (e->engage_regs == 1 && !contact) hipLaunchKernelGGL((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, st, p, actions, o);
-  else if (e->engage_regs == 1) hipLaunchKernelGGL((engage_kernel<2, 9, true>), dim3(b2), dim3(64), 0, st, p, actions, o);
   else if (e->engage_regs == 2 && !contact) hipLaunchKernelGGL((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, st, p, actions, o);
+#ifndef TE_DEBUG_STAMPS  // the stamp build leaves the contact variants out (the compiler rejects them next to the stamp stores)
+  else if (e->engage_regs == 1) hipLaunchKernelGGL((engage_kernel<2, 9, true>), dim3(b2), dim3(64), 0, st, p, actions, o);
   else if (e->engage_regs == 2) hipLaunchKernelGGL((engage_kernel<6, 12, true>), dim3(b2), dim3(64), 0, st, p, actions, o);
+#endif
   else if (e->engage_regs == 5) hipLaunchKernelGGL((engage_kernel<7, 30>), dim3(b2), dim3(64), 0, st, p, actions, o);
   else if (e->engage_regs == 3) hipLaunchKernelGGL((engage_stage02_kernel<2, 8>), dim3(b2), dim3(64), 0, st, p, actions, o);
   else if (e->engage_regs == 4) hipLaunchKernelGGL(engage_stage01_kernel, dim3(b2), dim3(64), 0, st, p, actions, o);
@@ -1391,7 +1438,7 @@ __attribute__((visibility("default"))) int te_profile_end(te_env* e, float* subs
 // Diagnostic builds (-DTE_DEBUG_STAMPS): s_memrealtime (100 MHz) stamps one workgroup wrote at its phase
 // boundaries during the last launch; all zeros in a normal build.
 __attribute__((visibility("default"))) int te_debug_stamps(te_env* e, uint64_t* out_host, int32_t n) {
-  if (!e || !out_host || n < 1 || (size_t)n > 64 + 16 * (size_t)(e->p.Npad / kEPB + 1)) return fail("te_debug_stamps: bad argument");
+  if (!e || !out_host || n < 1 || (size_t)n > (e->dbg_words ? e->dbg_words : 64 + 16 * (size_t)(e->p.Npad / kEPB + 1))) return fail("te_debug_stamps: bad argument");
   memset(out_host, 0, (size_t)n * sizeof(uint64_t));
   if (!e->p.dbg) return 0;
   DeviceGuard guard(e->device);

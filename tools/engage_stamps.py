@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-wave phase times of engage_kernel (te_engage.hpp) over a rollout.  Needs a -DTE_DEBUG_STAMPS build:
-    python -c "from dronechase_amd.build import build_library; build_library(force=True, extra_flags=['-DTE_DEBUG_STAMPS'])"
+    python -c "from dronechase_amd.build import build_library; build_library(force=True, extra_flags=['-DTE_DEBUG_STAMPS', '-DTE_NO_LSTAMP'])"
     python tools/engage_stamps.py [N] [steps]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
