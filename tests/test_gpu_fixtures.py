@@ -2,6 +2,8 @@
 not with the oracle: te_set_state -> te_step / te_observe -> outputs + te_get_state.
 
   task_logic.npz     OffsetHandler + EntitiesManager + Gun + Exp03_vFinal_Task.on_step_middle / on_step_end on 288 arenas
+  stage_logic.npz    stage02: L3Stage1.on_step_middle / on_step_end + level3 OffsetHandler / QuadcopterManager / Gun on 224 arenas;
+                     stage01: PyflytL2EnviromentModifiedV2 reward / termination / replace_invader_if_close on 160 arenas
   lidar_math.npz     LidarMath binning of 1 000 body-frame vectors; add_features (closer wins) on 50 feature lists
   gun.npz            Gun traces (can_fire, munition, cooldown, 3-float state)
   kamikaze.npz       KamikazeNavigator (air-combat-only and cone variants): next state + command
@@ -13,6 +15,7 @@ import numpy as np
 import pytest
 
 from dronechase_amd import config as K
+from tests import _stage_logic as S
 from tests import _task_logic as T
 from tests._blob import Blob
 
@@ -51,6 +54,30 @@ def test_task_logic_fixture_through_the_c_abi(golden):
     _, _, _, reward, done, info = env.step(_zeros(n), terminal=False)
     checked = T.compare(g, reward.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy(), _state(env, n, cfg.n_drones))
     assert checked == n >= 200
+    env.close()
+
+
+def test_stage02_logic_fixture_through_the_c_abi(golden):
+    from dronechase_amd import default_config
+    g = golden("stage_logic.npz")
+    cfg = S.config02(default_config, g)
+    env = _gpu(cfg)
+    n = cfg.n_envs
+    _load(env, S.build_blob02(g, env.state_words()))
+    _, _, _, reward, done, _ = env.step(_zeros(n), terminal=False)
+    assert S.compare02(g, reward.cpu().numpy(), done.cpu().numpy(), _state(env, n, cfg.n_drones)) == n >= 200
+    env.close()
+
+
+def test_stage01_logic_fixture_through_the_c_abi(golden):
+    from dronechase_amd import default_config
+    g = golden("stage_logic.npz")
+    cfg = S.config01(default_config, g)
+    env = _gpu(cfg)
+    n = cfg.n_envs
+    _load(env, S.build_blob01(g, env.state_words()))
+    _, _, _, reward, done, _ = env.step(_zeros(n), terminal=False)
+    assert S.compare01(g, reward.cpu().numpy(), done.cpu().numpy(), _state(env, n, 3)) == n >= 150
     env.close()
 
 
