@@ -65,3 +65,48 @@ def compare(g, reward, done, info, after: Blob, reward_atol=2e-3):
             assert after.ei(e, "ROUND") == g["round_after"][e], e
         assert after.ei(e, "STEP") == g["step"][e], e
     return n
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# tests/golden/drive_logic.npz (gen_drive_logic.py): the reference's LoyalWingmanBehaviorTree and KamikazeNavigator run inside
+# Exp03_vFinal_Task around one env.step: the commands of step t (update #1) and of step t+1 (update #2), the invaders' states after each.
+def build_blob_drive(g, words: int) -> Blob:
+    b = build_blob(g, words)
+    n, P, I = len(g["step"]), int(g["P"]), int(g["I"])
+    for e in range(n):
+        for j in range(I):
+            b.set_i(e, P + j, "NAV_STATE", int(g["nav"][e, j]))
+        b.set_f(e, 1, "FORMATION", g["formation"][e])
+    return b
+
+
+def setpoint_of(cmd):
+    """Quadcopter.convert_command_to_setpoint (quadcopter.py:379-396; pinned by tests/golden/command.npz): unit(direction) * magnitude as [vx, vy, 0, vz]"""
+    d = np.asarray(cmd[:3], np.float64)
+    n = np.linalg.norm(d)
+    v = cmd[3] * d / (n if n > 0 else 1.0)
+    return np.array([v[0], v[1], 0.0, v[2]])
+
+
+def compare_commands(g, after: Blob, which: int, still_armed=None, atol=2e-6):
+    """Set-point words and invader states after product step `which` (1: the commands of step t, 2: of step t+1) against the reference's
+    navigators.  Only drones that are still armed when the state is read can be compared (disarm clears the set-point), and update #2 only
+    in arenas where the step neither ended the episode nor started a new round.  Returns (commands compared, states compared)."""
+    n, P, I = len(g["step"]), int(g["P"]), int(g["I"])
+    D = P + I
+    cmd, nav = g["cmd%d" % which], g["nav%d" % which]
+    n_cmd = n_nav = 0
+    for e in range(n):
+        if which == 2 and not g["comparable"][e]:
+            continue
+        for s in range(1, D):                       # slot 0 is the RL agent: its set-point is the action
+            if np.isnan(cmd[e, s, 0]) or not after.i(e, s, "ARMED"):
+                continue
+            if which == 1 and (not g["armed_after"][e, s] or (s >= P and not g["comparable"][e])):   # a new round re-arms invaders at fresh positions
+                continue
+            np.testing.assert_allclose(after.f(e, s, "SETPOINT", 4), setpoint_of(cmd[e, s]), rtol=0, atol=atol, err_msg=f"arena {e} slot {s} update {which}")
+            n_cmd += 1
+            if s >= P:
+                assert after.i(e, s, "NAV_STATE") == nav[e, s - P], (e, s, which)
+                n_nav += 1
+    return n_cmd, n_nav

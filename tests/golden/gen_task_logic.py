@@ -82,7 +82,8 @@ def by_path(name, rel):
     return mod
 
 
-def load_reference():
+def load_reference(real_tree=False):
+    """real_tree: load the reference's LoyalWingmanBehaviorTree itself (pure numpy once `Quadcopter` is the stand-in) instead of its tripwire: gen_drive_logic.py"""
     from core.entities.entity_type import EntityType
 
     # --- stand-ins for what cannot be imported here -------------------------------------------------------------
@@ -104,6 +105,12 @@ def load_reference():
         armed = property(lambda self: self._armed)
         inertial_data = property(lambda self: self._inertial)
         gun_state = property(lambda self: self.gun.get_state())
+
+        is_gun_available = property(lambda self: self.gun.is_available())          # quadcopter.py:356-362
+        is_munition_available = property(lambda self: self.gun.has_munition())
+
+        def drive(self, motion_command, show_name_on=False):   # quadcopter.py:398-413 (recorded; the set-point conversion is pinned elsewhere)
+            self.last_drive = np.array(motion_command, float)
 
         def shoot(self):
             return self.gun.shoot()
@@ -129,9 +136,12 @@ def load_reference():
     m = types.ModuleType("core.entities.immovable_structures.immovable_structures")
     m.ImmovableStructures = tripwire("ImmovableStructures")
     sys.modules[m.__name__] = m
-    m = types.ModuleType("core.entities.navigators.loyalwingman_navigator")
-    m.LoyalWingmanBehaviorTree = tripwire("LoyalWingmanBehaviorTree", allow=("reset",))
-    sys.modules[m.__name__] = m
+    if real_tree:
+        by_path("core.entities.navigators.loyalwingman_navigator", "core/entities/navigators/loyalwingman_navigator.py")
+    else:
+        m = types.ModuleType("core.entities.navigators.loyalwingman_navigator")
+        m.LoyalWingmanBehaviorTree = tripwire("LoyalWingmanBehaviorTree", allow=("reset",))
+        sys.modules[m.__name__] = m
     # threatengage/__init__.py imports gymnasium: empty packages instead, real modules loaded by path below
     base = "threatengage.environments.level4.components"
     for name in ("threatengage", "threatengage.environments", "threatengage.environments.level4", base, base + ".utils",
@@ -266,8 +276,57 @@ def make_arenas(rng, n):
     return A, n_scripted
 
 
+def setup_arena(mods, ai, a, publish=True):
+    """One arena as the reference's objects at the moment the environment would call task.on_step_middle(): registry, guns, task counters,
+    the step broadcast delivered, the offsets of the episode start.  Returns (hub, mgr, drones, task, step, draws)."""
+    EntityType, gun_mod, HQ, em_mod, oh_mod, task_mod = mods
+    from core.notification_system.message_hub import MessageHub
+    from core.notification_system.topics_enum import TopicsEnum
+    hub = MessageHub(); hub._initialize()                      # fresh subscriptions per arena (thread-local singleton)
+    mgr = em_mod.EntitiesManager(); mgr._initialize()
+    mgr.setup_simulation(types.SimpleNamespace(active_drones={}))
+    drones = {}
+    for j in range(I):                                         # invaders first (on_env_init order), ids 1..I
+        drones[P + j] = HQ(1 + j, EntityType.LOITERINGMUNITION)
+    for p in range(P):
+        drones[p] = HQ(10 + p, EntityType.LOYALWINGMAN)
+    for s in list(range(P, D)) + list(range(P)):
+        mgr.drone_registry[drones[s].id] = drones[s]
+    task = task_mod.Exp03_vFinal_Task(mgr, DOME)
+    assert (task.NUM_PURSUERS, task.NUM_INVADERS, task.MAX_NUMBER_OF_ROUNDS) == (P, I, I)
+    for p in range(P):
+        drones[p].set_munition(task.munition_per_defender)     # spawn_pursuer_squad (exp03_vFinal_task.py:641-642)
+    for s in range(D):
+        d = drones[s]
+        d._inertial["position"] = a["pos"][s].copy()
+        if s == 0:
+            d._inertial["velocity"] = np.array(a["vel"], float)
+        if a["armed"][s]:
+            mgr.arm_by_quadcopter(d)
+    for p in range(P):
+        g = drones[p].gun
+        g.munition = int(a["munition"][p]); g.last_fired_step = float(a["last_fired"][p])
+    task.MAX_STEP = int(a["max_step"]); task.current_round = int(a["round"])
+    task.last_closest_distance = float(a["last_dist"])
+    task.agent_kills, task.allies_kills, task.deads = (int(x) for x in a["kills"])
+    task.offset_handler.on_episode_start()
+    step = int(a["step"])
+    if publish:
+        broadcast_step(hub, step)
+        assert task.current_step == step and drones[0].gun.current_step == step
+    draws = [philox_u01(ai, p, step) for p in range(P)]
+    return hub, mgr, drones, task, step, draws
+
+
+def broadcast_step(hub, step):
+    from core.notification_system.topics_enum import TopicsEnum
+    hub.publish(topic=TopicsEnum.AGENT_STEP_BROADCAST, message={"step": step, "timestep": 1 / 15},
+                message_context=hub.create_message_context(publisher_id=0, step=step))
+
+
 def main(n=288):
-    EntityType, gun_mod, HQ, em_mod, oh_mod, task_mod = load_reference()
+    mods = load_reference()
+    EntityType, gun_mod, HQ, em_mod, oh_mod, task_mod = mods
     from core.notification_system.message_hub import MessageHub
     from core.notification_system.topics_enum import TopicsEnum
 
@@ -286,39 +345,7 @@ def main(n=288):
                            "outside", "counts", "reward", "done", "armed_mid", "munition_after", "last_fired_after", "max_step_after",
                            "kills_after", "last_dist_after", "info", "round_after", "armed_after", "shots_fired")}
     for ai, a in enumerate(arenas):
-        hub = MessageHub(); hub._initialize()                      # fresh subscriptions per arena (thread-local singleton)
-        mgr = em_mod.EntitiesManager(); mgr._initialize()
-        mgr.setup_simulation(types.SimpleNamespace(active_drones={}))
-        drones = {}
-        for j in range(I):                                         # invaders first (on_env_init order), ids 1..I
-            drones[P + j] = HQ(1 + j, EntityType.LOITERINGMUNITION)
-        for p in range(P):
-            drones[p] = HQ(10 + p, EntityType.LOYALWINGMAN)
-        for s in list(range(P, D)) + list(range(P)):
-            mgr.drone_registry[drones[s].id] = drones[s]
-        task = task_mod.Exp03_vFinal_Task(mgr, DOME)
-        assert (task.NUM_PURSUERS, task.NUM_INVADERS, task.MAX_NUMBER_OF_ROUNDS) == (P, I, I)
-        for p in range(P):
-            drones[p].set_munition(task.munition_per_defender)     # spawn_pursuer_squad (exp03_vFinal_task.py:641-642)
-        for s in range(D):
-            d = drones[s]
-            d._inertial["position"] = a["pos"][s].copy()
-            if s == 0:
-                d._inertial["velocity"] = np.array(a["vel"], float)
-            if a["armed"][s]:
-                mgr.arm_by_quadcopter(d)
-        for p in range(P):
-            g = drones[p].gun
-            g.munition = int(a["munition"][p]); g.last_fired_step = float(a["last_fired"][p])
-        task.MAX_STEP = int(a["max_step"]); task.current_round = int(a["round"])
-        task.last_closest_distance = float(a["last_dist"])
-        task.agent_kills, task.allies_kills, task.deads = (int(x) for x in a["kills"])
-        task.offset_handler.on_episode_start()
-        step = int(a["step"])
-        hub.publish(topic=TopicsEnum.AGENT_STEP_BROADCAST, message={"step": step, "timestep": 1 / 15},
-                    message_context=hub.create_message_context(publisher_id=0, step=step))
-        assert task.current_step == step and drones[0].gun.current_step == step
-        draws = [philox_u01(ai, p, step) for p in range(P)]
+        hub, mgr, drones, task, step, draws = setup_arena(mods, ai, a)
         # a pursuer consumes its draw only if it fires; shots are processed in pursuer order
         oh = task.offset_handler
         oh.on_middle_step()

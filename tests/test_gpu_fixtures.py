@@ -2,6 +2,7 @@
 not with the oracle: te_set_state -> te_step / te_observe -> outputs + te_get_state.
 
   task_logic.npz     OffsetHandler + EntitiesManager + Gun + Exp03_vFinal_Task.on_step_middle / on_step_end on 288 arenas
+  drive_logic.npz    LoyalWingmanBehaviorTree + KamikazeNavigator inside Exp03_vFinal_Task around one env.step (commands of step t and t+1) on 320 arenas
   stage_logic.npz    stage02: L3Stage1.on_step_middle / on_step_end + level3 OffsetHandler / QuadcopterManager / Gun on 224 arenas;
                      stage01: PyflytL2EnviromentModifiedV2 reward / termination / replace_invader_if_close on 160 arenas
   lidar_math.npz     LidarMath binning of 1 000 body-frame vectors; add_features (closer wins) on 50 feature lists
@@ -54,6 +55,23 @@ def test_task_logic_fixture_through_the_c_abi(golden):
     _, _, _, reward, done, info = env.step(_zeros(n), terminal=False)
     checked = T.compare(g, reward.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy(), _state(env, n, cfg.n_drones))
     assert checked == n >= 200
+    env.close()
+
+
+def test_drive_logic_fixture_through_the_c_abi(golden):
+    """The ally's behaviour tree (prepare_slot in the engage kernel's epilogue, prepare_commands_kernel after te_set_state) and the invaders'
+    state machine (top of the sub-step kernel) against the reference's navigators: two steps without physics, set-point words after each."""
+    from dronechase_amd import default_config
+    g = golden("drive_logic.npz")
+    cfg = T.config(default_config, g)
+    env = _gpu(cfg)
+    n, D = cfg.n_envs, cfg.n_drones
+    _load(env, T.build_blob_drive(g, env.state_words()))
+    env.step(_zeros(n), terminal=False)
+    c1, s1 = T.compare_commands(g, _state(env, n, D), 1)
+    env.step(_zeros(n), terminal=False)
+    c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
+    assert c1 >= 600 and s1 >= 400 and c2 >= 500 and s2 >= 400, (c1, s1, c2, s2)
     env.close()
 
 
