@@ -822,6 +822,8 @@ struct te_env {
     float *t_lidar = nullptr, *t_inertial = nullptr, *t_last_action = nullptr;
     uint8_t *done = nullptr, *mask = nullptr; int32_t* info = nullptr; uint32_t* blob = nullptr;
   } hs;
+  std::vector<int32_t> done_idx;   // host I/O: the done envs of the step, and the host landing zone of their terminal rows
+  std::vector<char> done_rows;
   int fill_mode = 1;       // TE_FILL_MODE: 0 pointer loop, 1 scalar buffer loop, 2 + s_setprio 3
   int n_fill_waves = 256;  // fill waves of the sub-step kernel: one per CU of an MI355X; four per CU for the six-sphere background of
                            // level5, where ~9 flight waves per SIMD would leave one fill wave too small a share of the issue slots
@@ -870,7 +872,13 @@ static void launch_census(te_env* e, hipStream_t st) {
 
 // ---- cfg.io_location == TE_IO_HOST: the caller's pointers are HOST pointers (what an SB3 SubprocVecEnv-style caller holds).  Inputs
 // are copied to the staging buffers, the device entry point runs on them, outputs are copied back and the stream is drained: the
-// call returns with the host buffers filled.  The observation (4.1 KB per env) crosses PCIe every step: ~15 M env-steps/s at best.
+// call returns with the host buffers filled.  The observation (4.1 KB per env) crosses PCIe every step: 12.4 M env-steps/s at 65 536 envs
+// with pageable numpy arrays, 13.0 M with pinned ones (52-54 GB/s, tools/host_io_bench.py).
+// rows[idx[b]] -> out[b] (row_words floats each): the terminal observations of the done envs, packed for one PCIe copy
+__global__ __launch_bounds__(64) void gather_rows_kernel(const float* __restrict__ rows, float* __restrict__ out, const int32_t* __restrict__ idx, int row_words) {
+  const size_t from = (size_t)idx[blockIdx.x] * row_words, to = (size_t)blockIdx.x * row_words;
+  for (int k = threadIdx.x; k < row_words; k += 64) out[to + k] = rows[from + k];
+}
 static bool host_io(const te_env* e) { return e && e->p.cfg.io_location == TE_IO_HOST; }
 #define TE_H2D(dst, src, bytes) do { if ((src) && (bytes)) TE_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
 #define TE_D2H(dst, src, bytes) do { if ((dst) && (bytes)) TE_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, st)); } while (0)
@@ -1259,9 +1267,39 @@ __attribute__((visibility("default"))) int te_step(te_env* e, const float* actio
                   terminal_last_action ? h.t_last_action : nullptr, nullptr, stream)) return 1;
     TE_D2H(obs_lidar, h.lidar, N * lw); TE_D2H(obs_inertial, h.inertial, N * 60); TE_D2H(obs_last_action, h.last_action, N * 16);
     TE_D2H(reward, h.reward, N * 4); TE_D2H(done, h.done, N); TE_D2H(info, h.info, N * 16);
-    // terminal rows are written only for envs that are done: copy whole buffers, the caller reads the rows of its done envs
-    TE_D2H(terminal_lidar, h.t_lidar, N * lw); TE_D2H(terminal_inertial, h.t_inertial, N * 60); TE_D2H(terminal_last_action, h.t_last_action, N * 16);
     TE_HIP(hipStreamSynchronize(st));
+    // terminal rows are defined only for envs that are done (include/threatengage.h): ~1 % of the envs per step.  Copying the three
+    // buffers whole doubled the PCIe bytes of a step (6.5 instead of 12.5 M env-steps/s at 65 536 envs, tools/host_io_bench.py): the done
+    // rows are gathered on the device (into the observation staging, whose copy has landed), cross in one piece each and are
+    // scattered into the caller's arrays here.
+    if (terminal_lidar || terminal_inertial || terminal_last_action) {
+      std::vector<int32_t>& idx = e->done_idx;
+      idx.clear();
+      for (size_t i = 0; i < N; ++i) if (done[i]) idx.push_back((int32_t)i);
+      const size_t n = idx.size();
+      if (n) {
+        const size_t row[3] = {terminal_lidar ? lw : 0, terminal_inertial ? (size_t)60 : 0, terminal_last_action ? (size_t)16 : 0};
+        const float* src[3] = {h.t_lidar, h.t_inertial, h.t_last_action};
+        float* tmp[3] = {h.lidar, h.inertial, h.last_action};
+        float* dst[3] = {terminal_lidar, terminal_inertial, terminal_last_action};
+        e->done_rows.resize(n * (row[0] + row[1] + row[2]));
+        TE_HIP(hipMemcpyAsync(h.info, idx.data(), n * 4, hipMemcpyHostToDevice, st));   // the info staging is free again too
+        char* land = e->done_rows.data();
+        for (int k = 0; k < 3; ++k) {
+          if (!row[k]) continue;
+          hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(64), 0, st, src[k], tmp[k], h.info, (int)(row[k] / 4));
+          TE_HIP(hipMemcpyAsync(land, tmp[k], n * row[k], hipMemcpyDeviceToHost, st));
+          land += n * row[k];
+        }
+        TE_HIP(hipStreamSynchronize(st));
+        land = e->done_rows.data();
+        for (int k = 0; k < 3; ++k) {
+          if (!row[k]) continue;
+          for (size_t j = 0; j < n; ++j) memcpy((char*)dst[k] + (size_t)idx[j] * row[k], land + j * row[k], row[k]);
+          land += n * row[k];
+        }
+      }
+    }
     return 0;
   }
   return step_impl(e, actions, obs_lidar, e ? (size_t)lidar_words(e->p.cfg) : 0, obs_inertial, obs_last_action, reward, done, info, terminal_lidar,
