@@ -43,22 +43,51 @@ def make_config(task: str, num_envs: int, dome_radius: Optional[float] = None, r
 
 
 class LazyInfos(Sequence):
-    """infos without materialising N dicts per step: dicts are built on access."""
+    """infos without materialising N dicts per step: dicts are built on access.  `info` / `done` may be zero-argument callables
+    (output="torch": nothing crosses PCIe, and the stream is not drained, unless somebody actually reads an info)."""
 
-    def __init__(self, info: np.ndarray, done: np.ndarray, terminal: Optional[Dict[str, np.ndarray]]):
+    def __init__(self, info, done, terminal):
         self._info, self._done, self._terminal = info, done, terminal
+        self._n = None if callable(done) else len(done)
+
+    def _host(self):
+        if callable(self._info):
+            self._info, self._done = self._info(), self._done()
+            if callable(self._terminal):
+                self._terminal = self._terminal(self._done)
+        return self._info, self._done
 
     def __len__(self):
-        return len(self._done)
+        return len(self._host()[1]) if self._n is None else self._n
 
     def __getitem__(self, i):
         if isinstance(i, slice):
             return [self[j] for j in range(*i.indices(len(self)))]
-        d = dict(zip(INFO_KEYS, (int(v) for v in self._info[i])))
-        d["TimeLimit.truncated"] = False  # the reference always returns truncated=False (exp03_vFinal_environment.py:167)
-        if self._done[i] and self._terminal is not None:
+        info, done = self._host()
+        r = info[i]
+        d = {"agent_kills": int(r[0]), "allies_kills": int(r[1]), "deads": int(r[2]), "current_wave": int(r[3]),
+             "TimeLimit.truncated": False}  # the reference always returns truncated=False (exp03_vFinal_environment.py:167)
+        if done[i] and self._terminal is not None:
             d["terminal_observation"] = {k: v[i] for k, v in self._terminal.items()}
         return d
+
+    def materialise(self) -> List[Dict[str, Any]]:
+        """The list of N dicts SB3 iterates over (infos="dicts"): one C-level conversion of the info rows, then a dict display per env."""
+        import gc
+
+        info, done = self._host()
+        a, b, c, w = info.T.tolist()          # four lists of Python ints in one C-level pass each
+        on = gc.isenabled()
+        gc.disable()                          # N fresh containers would trigger a generation-2 pass over the previous steps' dicts every few hundred
+        try:
+            out = [{"agent_kills": x, "allies_kills": y, "deads": z, "current_wave": r, "TimeLimit.truncated": False} for x, y, z, r in zip(a, b, c, w)]
+        finally:
+            if on:
+                gc.enable()
+        if self._terminal is not None:
+            for i in np.flatnonzero(done):
+                out[i]["terminal_observation"] = {k: v[int(i)] for k, v in self._terminal.items()}
+        return out
 
 
 class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
@@ -95,16 +124,34 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
         self.lw_driver = None
 
     # ------------------------------------------------------------------ helpers
-    def _to_out(self, t):
-        return t if self.output == "torch" else t.detach().cpu().numpy()
+    def _to_host(self, tensors):
+        """Device tensors -> numpy arrays with ONE drain of the stream: each lands in a fresh pinned block of torch's caching host allocator
+        (the arrays are the caller's to keep; blocks of dropped arrays are reused), copied asynchronously.  `t.cpu()` per tensor went through
+        pageable memory: 33 ms per step at 65 536 envs instead of 5 (tools/vecenv_bench.py)."""
+        import torch
+
+        outs = []
+        on_gpu = False
+        for t in tensors:
+            t = t.detach()
+            if t.device.type == "cpu":          # stub backends of the CPU tests
+                outs.append(t)
+                continue
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            outs.append(h)
+            on_gpu = True
+        if on_gpu:
+            torch.cuda.current_stream(self.backend.device).synchronize()
+        return [h.numpy() for h in outs]
+
+    def _obs_keys(self):
+        return ("stacked_spheres", "validity_mask", "inertial_data", "last_action") if self.stacked else ("lidar", "inertial_data", "last_action")
 
     def _obs(self, *t):
         if self.stacked:
-            stacked, mask, inertial, last_action = t
-            return {"stacked_spheres": self._to_out(stacked), "validity_mask": self._to_out(mask.bool()),
-                    "inertial_data": self._to_out(inertial), "last_action": self._to_out(last_action)}
-        lidar, inertial, last_action = t
-        return {"lidar": self._to_out(lidar), "inertial_data": self._to_out(inertial), "last_action": self._to_out(last_action)}
+            t = (t[0], t[1].bool(), t[2], t[3])
+        return dict(zip(self._obs_keys(), t if self.output == "torch" else self._to_host(t)))
 
     def _as_device_actions(self, actions):
         import torch
@@ -136,28 +183,37 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
             self._drive_ally()
         *obs_t, reward, done, info = (b.step_stacked if self.stacked else b.step)(self._actions, terminal=True)
         self._actions = None
-        obs = self._obs(*obs_t)
-        done_np = done.detach().cpu().numpy().astype(bool)
-        info_np = info.detach().cpu().numpy()
-        terminal = None
-        if done_np.any():
-            tbuf = ({"stacked_spheres": b.t_stacked, "validity_mask": b.t_mask.bool()} if self.stacked else {"lidar": b.t_lidar})
-            tbuf.update({"inertial_data": b.t_inertial, "last_action": b.t_last_action})
-            if self.output == "torch":
-                terminal = tbuf
-            else:  # copy only the rows that are valid
-                idx = np.flatnonzero(done_np)
-                import torch
+        if self.stacked:
+            obs_t = [obs_t[0], obs_t[1].bool(), obs_t[2], obs_t[3]]
+        tbuf = ({"stacked_spheres": b.t_stacked, "validity_mask": b.t_mask.bool()} if self.stacked else {"lidar": b.t_lidar})
+        tbuf.update({"inertial_data": b.t_inertial, "last_action": b.t_last_action})
+        if self.output == "torch":
+            # nothing leaves the device here: infos read done / info (one small copy, which drains the stream) when somebody indexes them
+            host = {}
 
-                ti = torch.from_numpy(idx).to(b.device)
-                rows = {k: v[ti].cpu().numpy() for k, v in tbuf.items()}
-                terminal = {k: _ScatterRows(idx, v, self.num_envs) for k, v in rows.items()}
+            def both():
+                if not host:
+                    host["info"], d = self._to_host([info, done])
+                    host["done"] = d.astype(bool)
+                return host
+            infos = LazyInfos(lambda: both()["info"], lambda: both()["done"], tbuf)
+            if self.infos_mode == "dicts":
+                infos = infos.materialise()
+            return dict(zip(self._obs_keys(), obs_t)), reward, done.bool(), infos
+        *obs_np, rew, done_u8, info_np = self._to_host([*obs_t, reward, done, info])
+        done_np = done_u8.astype(bool)
+        terminal = None
+        if done_np.any():  # copy only the rows that are valid
+            import torch
+
+            idx = np.flatnonzero(done_np)
+            ti = torch.from_numpy(idx).to(b.device)
+            rows = self._to_host([v[ti] for v in tbuf.values()])
+            terminal = {k: _ScatterRows(idx, v, self.num_envs) for k, v in zip(tbuf.keys(), rows)}
         infos = LazyInfos(info_np, done_np, terminal)
         if self.infos_mode == "dicts":
-            infos = list(infos)
-        rew = self._to_out(reward)
-        dones = done.bool() if self.output == "torch" else done_np
-        return obs, rew, dones, infos
+            infos = infos.materialise()
+        return dict(zip(self._obs_keys(), obs_np)), rew, done_np, infos
 
     def step(self, actions):
         self.step_async(actions)

@@ -90,6 +90,28 @@ def test_pipeline_factory_whitelists_kwargs():
         RLP.create_vectorized_environment(dict, {}, n_envs=2, backend=StubBackend(2))
 
 
+def test_torch_output_reads_nothing_back_until_an_info_is_indexed():
+    """output="torch": observations, rewards and dones stay tensors and the infos are a view that fetches done / info on first access
+    (the on-device rollout never pays for them); infos="dicts" and infos="lazy" agree entry for entry."""
+    import torch
+    from dronechase_amd.vec_env import LazyInfos, ThreatEngageVecEnv
+    n = 5
+    a = torch.zeros((n, 4)); a[3, 0] = 1.0
+    v = ThreatEngageVecEnv("stage03", num_envs=n, backend=StubBackend(n), output="torch", infos="lazy")
+    v.reset()
+    obs, rew, dones, infos = v.step(a)
+    assert isinstance(obs["lidar"], torch.Tensor) and isinstance(rew, torch.Tensor) and dones.dtype == torch.bool
+    assert isinstance(infos, LazyInfos) and callable(infos._info)          # not fetched yet
+    assert len(infos) == n and not callable(infos._info)                    # ... now it is
+    assert infos[3]["terminal_observation"]["lidar"].shape == (3, 13, 26) and "terminal_observation" not in infos[0]
+    d = ThreatEngageVecEnv("stage03", num_envs=n, backend=StubBackend(n), output="torch", infos="dicts")
+    d.reset()
+    _, _, _, di = d.step(a)
+    assert isinstance(di, list) and [set(x) for x in di] == [set(infos[i]) for i in range(n)]
+    assert all(di[i][k] == infos[i][k] for i in range(n) for k in ("agent_kills", "allies_kills", "deads", "current_wave", "TimeLimit.truncated"))
+    assert all(type(di[i]["deads"]) is int for i in range(n))
+
+
 @pytest.mark.gpu
 def test_vecenv_on_gpu_matches_batched_env():
     import torch
