@@ -45,6 +45,14 @@ __global__ __launch_bounds__(256) void patch_par(float* lidar, int N, int H) {
   const float r = 0.25f + 0.001f * h;
   for (int ch = 0; ch < 3; ++ch) lidar[(size_t)env * TILE + ch * CELLS + cell] = ch == 0 ? r : ch == 1 ? 0.2f : 0.1f;
 }
+// one thread per (env, hit, channel), ENV-major: the 3 H stores of an env leave in the same store instruction (same 4 KB tile, same DRAM pages)
+__global__ __launch_bounds__(256) void patch_envmajor(float* lidar, int N, int H) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= N * H * 3) return;
+  const int env = t / (H * 3), r = t - env * H * 3, h = r / 3, ch = r - h * 3;
+  const int cell = hashu(env * 16 + h) % CELLS;
+  lidar[(size_t)env * TILE + ch * CELLS + cell] = ch == 0 ? 0.25f + 0.001f * h : ch == 1 ? 0.2f : 0.1f;
+}
 // full 128-byte lines: half a wave (32 lanes) writes the aligned line of one patch, ones elsewhere (NOT exact when two hits share a
 // line: traffic experiment only)
 __global__ __launch_bounds__(64) void patch_line(float* lidar, int N, int H) {
@@ -81,7 +89,7 @@ int main(int argc, char** argv) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int nt = 1; nt >= 0; --nt)
     for (int H : {2, 3, 6, 10})
-      for (int mode = 0; mode < 8; ++mode) {
+      for (int mode = 0; mode < 9; ++mode) {
         float tot = 0;
         for (int it = 0; it < 6; ++it) {
           fill<<<2048, 256>>>((f4*)buf, floats / 4, nt);
@@ -93,12 +101,13 @@ int main(int argc, char** argv) {
           else if (mode == 4) patch_line<<<N / 64, 64>>>(buf, N, H);
           else if (mode == 5) patch_sector<8><<<(unsigned)(((size_t)N * H * 3 * 8 + 255) / 256), 256>>>(buf, N, H);
           else if (mode == 6) patch_sector<16><<<(unsigned)(((size_t)N * H * 3 * 16 + 255) / 256), 256>>>(buf, N, H);
+          else if (mode == 8) patch_envmajor<<<(N * H * 3 + 255) / 256, 256>>>(buf, N, H);
           else patch_sector<32><<<(unsigned)(((size_t)N * H * 3 * 32 + 255) / 256), 256>>>(buf, N, H);
           hipEventRecord(b); hipEventSynchronize(b);
           float ms; hipEventElapsedTime(&ms, a, b);
           if (it) tot += ms;
         }
-        printf("%s fill, %2d hits/env, %-6s: %6.1f us\n", nt ? "nontemporal" : "cached     ", H, mode == 0 ? "dword" : mode == 1 ? "quad" : mode == 2 ? "seg64" : mode == 3 ? "par" : mode == 4 ? "line128" : mode == 5 ? "sect32" : mode == 6 ? "sect64" : "sect128", tot / 5 * 1e3);
+        printf("%s fill, %2d hits/env, %-6s: %6.1f us\n", nt ? "nontemporal" : "cached     ", H, mode == 0 ? "dword" : mode == 1 ? "quad" : mode == 2 ? "seg64" : mode == 3 ? "par" : mode == 4 ? "line128" : mode == 5 ? "sect32" : mode == 6 ? "sect64" : mode == 7 ? "sect128" : "envmaj", tot / 5 * 1e3);
       }
   return 0;
 }
