@@ -76,8 +76,18 @@ def build_blob_drive(g, words: int) -> Blob:
     for e in range(n):
         for j in range(I):
             b.set_i(e, P + j, "NAV_STATE", int(g["nav"][e, j]))
-        b.set_f(e, 1, "FORMATION", g["formation"][e])
+        if g["formation"].ndim == 3:                 # level5_logic.npz: every wingman's formation point
+            for p in range(P):
+                b.set_f(e, p, "FORMATION", g["formation"][e, p])
+        else:
+            b.set_f(e, 1, "FORMATION", g["formation"][e])
     return b
+
+
+def config5(default_config, g, **extra):
+    n = len(g["step"])
+    return default_config("level5", n_envs=n, substeps=0, observe_lag=0, motor_noise=0, auto_reset=0, seed=int(g["seed"]),
+                          dome_radius=float(g["dome"]), **extra)
 
 
 def setpoint_of(cmd):
