@@ -61,4 +61,6 @@ class Blob:
         return sum((1 << d) for d in range(self.D) if self.i(env, d, "ARMED"))
 
     def refresh_snapshot(self, env):
-        self.set_ei(env, "SNAP_MASK", self.armed_mask(env))
+        m = self.armed_mask(env)
+        self.er[env, K.E["SNAP_MASK"]] = np.uint32(m & 0xFFFFFFFF)
+        self.er[env, K.E["SNAP_MASK_HI"]] = np.uint32(m >> 32)      # slots 32..63 (Level5DumbMultiObs: 37 drones)

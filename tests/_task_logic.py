@@ -98,6 +98,12 @@ def setpoint_of(cmd):
     return np.array([v[0], v[1], 0.0, v[2]])
 
 
+def config5_dumb(default_config, g, **extra):
+    n = len(g["step"])
+    return default_config("level5_dumb", n_envs=n, substeps=0, observe_lag=0, motor_noise=0, auto_reset=0, seed=int(g["seed"]),
+                          dome_radius=float(g["dome"]), **extra)
+
+
 def compare_commands(g, after: Blob, which: int, still_armed=None, atol=2e-6):
     """Set-point words and invader states after product step `which` (1: the commands of step t, 2: of step t+1) against the reference's
     navigators.  Only drones that are still armed when the state is read can be compared (disarm clears the set-point), and update #2 only
@@ -109,7 +115,7 @@ def compare_commands(g, after: Blob, which: int, still_armed=None, atol=2e-6):
     for e in range(n):
         if which == 2 and not g["comparable"][e]:
             continue
-        for s in range(1, D):                       # slot 0 is the RL agent: its set-point is the action
+        for s in range(0 if "agent_scripted" in g and int(g["agent_scripted"]) else 1, D):   # slot 0 is the RL agent (its set-point is the action) unless the task flies it too
             if np.isnan(cmd[e, s, 0]) or not after.i(e, s, "ARMED"):
                 continue
             if which == 1 and (not g["armed_after"][e, s] or (s >= P and not g["comparable"][e])):   # a new round re-arms invaders at fresh positions

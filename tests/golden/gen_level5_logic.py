@@ -12,9 +12,10 @@ level5 round table (12 invader slots, 8 rounds).  Same harness as gen_task_logic
 (`HarnessQuadcopter`: a data holder with the reference's Gun, `drive()` recorded), `ImmovableStructures` (tripwire) and the package
 __init__ files that import gymnasium; everything else is the reference's code.  Per arena the reference runs a whole step cycle
 (gen_drive_logic.py explains the two navigator updates); the fixture keeps its inputs, the commands of step t and t+1, reward,
-termination, info and the state after.  Slots: pursuer p = id 10 + p (the agent is id 10), invader j = id 1 + j.
+termination, info and the state after.  Slots: pursuer p = id 100 + p (the agent is id 100), invader j = id 1 + j.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_level5_logic.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_level5_logic.py              # level5_logic.npz       (Level5_Task)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_level5_logic.py level5_dumb  # level5_dumb_logic.npz  (Level5DumbMultiObjectTask, all seven wingmen scripted)
 """
 import os
 import sys
@@ -30,7 +31,22 @@ P, I = 6, 12          # level5_task.py:77-79
 D = P + I
 DOME = 20.0
 STATES = ("WaitState", "CollideWithWingman", "CollideWithBuilding")
-slot_of = lambda id_: id_ - 10 if id_ >= 10 else P + id_ - 1
+slot_of = lambda id_: id_ - 100 if id_ >= 100 else P + id_ - 1     # pursuer p = id 100 + p, invader j = id 1 + j
+# the two task files this generator runs: (module, class, P, I, rounds, munition, armed invaders in round r, agent flown by the tree, out file)
+KINDS = {
+    "level5": ("level5_task", "Level5_Task", 6, 12, 8, 20, lambda r: r, False, "level5_logic.npz"),
+    # Level5DumbMultiObjectTask (level5_dumb_multiobject_task.py:87-103): 6 + 1 wingmen ALL flown by the behaviour tree (:258-263), 5 invaders in round 1,
+    # one more per round up to 30, munition = all the invaders of an episode, its own reward (:452-559), the agent's death does not end the episode
+    "level5_dumb": ("level5_dumb_multiobject_task", "Level5DumbMultiObjectTask", 7, 30, 26, 455, lambda r: min(r - 1 + 5, 30), True, "level5_dumb_logic.npz"),
+}
+KIND = "level5"
+
+
+def configure(kind):
+    global KIND, P, I, D
+    KIND = kind
+    P, I = KINDS[kind][2], KINDS[kind][3]
+    D = P + I
 
 
 def load_reference():
@@ -92,7 +108,8 @@ def load_reference():
     G.by_path(base + ".normalization", rel + "normalization.py")
     G.by_path(base + ".tasks_management.task_progression", rel + "tasks_management/task_progression.py")
     em = G.by_path(base + ".entities_manager", rel + "entities_manager.py")
-    task = G.by_path(base + ".tasks_management.tasks.level5_task", rel + "tasks_management/tasks/level5_task.py")
+    mod = KINDS[KIND][0]
+    task = G.by_path(base + ".tasks_management.tasks." + mod, rel + "tasks_management/tasks/" + mod + ".py")
     nav = sys.modules["core.entities.navigators.loitering_munition_navigator_air_combat_only"]
     assert sys.modules["core.entities.navigators.loyalwingman_navigator"].__file__.startswith(G.REF)
     return EntityType, gun, HarnessQuadcopter, em, task, nav
@@ -105,6 +122,7 @@ def make_arenas(rng, n):
         a["armed"][:P] = (rng.rand(P) > 0.12).astype(np.int32)
         if rng.rand() < 0.06: a["armed"][1:P] = 0           # the agent alone: identify_closest_ally == -1
         a["armed"][0] = 1                       # the agent's death ends the episode: it is armed at the start of every step
+        if KINDS[KIND][7] and rng.rand() < 0.08: a["armed"][0] = 0   # ... except where the task goes on without it
         for p in range(P):
             a["pos"][p] = rng.uniform(-3, 3, 3) * [1, 1, 0.5] + [0, 0, 1.5]
         if rng.rand() < 0.15: a["pos"][1] = a["pos"][0] + rng.uniform(-0.5, 0.5, 3)
@@ -114,9 +132,10 @@ def make_arenas(rng, n):
         if rng.rand() < 0.3: a["pos"][0] *= rng.uniform(4.2, 9) / np.linalg.norm(a["pos"][0])
         for j in range(I):
             a["pos"][P + j] = [3.0 + j, -2.0 + 0.5 * j, 3.0]
-        k = rng.randint(1, 9)
-        a["round"] = int(rng.randint(k, 9))                       # rounds 1..8 arm `round` invaders; some are already dead
-        for j in rng.choice(a["round"], k, replace=False):
+        n_rounds, in_round = KINDS[KIND][4], KINDS[KIND][6]
+        a["round"] = int(rng.randint(1, n_rounds + 1))            # round r arms in_round(r) invaders; some are already dead
+        k = rng.randint(1, min(in_round(a["round"]), 10) + 1)
+        for j in rng.choice(in_round(a["round"]), k, replace=False):
             a["armed"][P + j] = 1
             u = rng.rand()
             anchor = a["pos"][rng.randint(0, P)]
@@ -126,7 +145,7 @@ def make_arenas(rng, n):
             elif u < 0.46: a["pos"][P + j] = dirn * rng.uniform(0.01, 0.18)
             elif u < 0.5: a["pos"][P + j] = dirn * rng.uniform(20.05, 22)
             else: a["pos"][P + j] = rng.uniform(-6, 6, 3) * [1, 1, 0.4] + [0, 0, 3]
-        a["munition"] = rng.choice([0, 1, 5, 20], P).astype(np.int32)
+        a["munition"] = rng.choice([0, 1, 5, KINDS[KIND][5]], P).astype(np.int32)
         a["step"] = int(rng.choice([5, 61, 150, 299, 300, 301, 420]))
         a["max_step"] = int(rng.choice([300, 400, 500]))
         a["last_fired"] = np.array([rng.choice([-60, a["step"] - 3, a["step"] - 60, a["step"] - 75]) for _ in range(P)], np.int32)
@@ -149,7 +168,9 @@ def make_arenas(rng, n):
     return A
 
 
-def main(n=256):
+def main(kind="level5", n=256):
+    configure(kind)
+    mod_name, cls_name, _, _, n_rounds, munition, in_round, agent_scripted, out_name = KINDS[kind]
     EntityType, gun_mod, HQ, em_mod, task_mod, nav_mod = load_reference()
     from core.notification_system.message_hub import MessageHub
     state_of = {"WaitState": nav_mod.WaitState, "CollideWithWingman": nav_mod.CollideWithWingmanState, "CollideWithBuilding": nav_mod.CollideWithBuildingState}
@@ -161,7 +182,7 @@ def main(n=256):
         def random(cls):
             return cls.queue.pop(0)
     gun_mod.random = Draw
-    rng = np.random.RandomState(20261008)
+    rng = np.random.RandomState(20261008 + (kind != "level5"))
     arenas = make_arenas(rng, n)
     keys = ("armed", "pos", "vel", "munition", "last_fired", "step", "max_step", "round", "last_dist", "kills", "nav", "formation", "cmd1", "nav1", "counts",
             "reward", "done", "info", "armed_mid", "armed_after", "munition_after", "last_fired_after", "max_step_after", "kills_after", "last_dist_after",
@@ -184,12 +205,12 @@ def main(n=256):
         for j in range(I):
             drones[P + j] = HQ(1 + j, EntityType.LOITERINGMUNITION)
         for p in range(P):
-            drones[p] = HQ(10 + p, EntityType.LOYALWINGMAN)
+            drones[p] = HQ(100 + p, EntityType.LOYALWINGMAN)
         for s in list(range(P, D)) + list(range(P)):
             mgr.drone_registry[drones[s].id] = drones[s]
-        assert mgr.set_agent(drone_id=10)
-        task = task_mod.Level5_Task(mgr, DOME)
-        assert (task.NUM_PURSUERS, task.NUM_INVADERS, task.MAX_NUMBER_OF_ROUNDS, task.MUNITION_PER_DEFENDER) == (P, I, 8, 20)
+        assert mgr.set_agent(drone_id=100)
+        task = getattr(task_mod, cls_name)(mgr, DOME)
+        assert (task.NUM_PURSUERS, getattr(task, "MAX_NUM_INVADERS", None) or task.NUM_INVADERS, task.MAX_NUMBER_OF_ROUNDS, task.MUNITION_PER_DEFENDER) == (P, I, n_rounds, munition)
         for p in range(P):
             drones[p].set_munition(task.MUNITION_PER_DEFENDER)
         for s in range(D):
@@ -222,9 +243,9 @@ def main(n=256):
         in_shoot = {slot_of(pid): ids for pid, ids in oh.identify_invaders_in_range(task.PURSUER_SHOOT_RANGE).items()}
         fired = np.array([int(a["armed"][p] and p in in_shoot and drones[p].gun.can_fire()) for p in range(P)], np.int32)
         Draw.queue = [draws[p] for p in range(P) if fired[p]]
-        ca = oh.identify_closest_ally(10)
+        ca = oh.identify_closest_ally(100)
         ca_slot = slot_of(ca) if ca != -1 else -1
-        tgt = oh.identify_closest_invader(10 if ca == -1 else ca)
+        tgt = oh.identify_closest_invader(100 if ca == -1 else ca)
         seen = {}
         orig = task.compute_reward
 
@@ -260,13 +281,13 @@ def main(n=256):
             rec[k].append(v)
     assert not G.TOUCHED, G.TOUCHED
     out = {k: np.array(v) for k, v in rec.items()}
-    np.savez_compressed(os.path.join(G.OUT, "level5_logic.npz"), P=P, I=I, dome=DOME, episode=G.EPISODE, seed=G.SEED, **out)
+    np.savez_compressed(os.path.join(G.OUT, out_name), P=P, I=I, agent_scripted=int(agent_scripted), dome=DOME, episode=G.EPISODE, seed=G.SEED, **out)
     c = out["counts"]
-    print(f"level5_logic: {len(arenas)} arenas; agent shots {int((c[:, 0] > 0).sum())}, ally shots {int((c[:, 1] > 0).sum())} (two or more allies {int((c[:, 1] > 1).sum())}), "
+    print(f"{out_name}: {len(arenas)} arenas; agent shots {int((c[:, 0] > 0).sum())}, ally shots {int((c[:, 1] > 0).sum())} (two or more allies {int((c[:, 1] > 1).sum())}), "
           f"explosions {int((c[:, 2] > 0).sum())}, ally suicides {int((c[:, 3] > 0).sum())}, agent suicides {int((c[:, 4] > 0).sum())}, done {int(out['done'].sum())}, "
           f"new rounds {int((out['round_after'] != out['round']).sum())}, comparable {int(out['comparable'].sum())}, closest ally != slot 1: {int((out['closest_ally'] > 1).sum())}, "
           f"no ally {int((out['closest_ally'] < 0).sum())}")
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "level5")   # one task file per process (the reference's singletons and module names are per kind)

@@ -4,6 +4,7 @@ not with the oracle: te_set_state -> te_step / te_observe -> outputs + te_get_st
   task_logic.npz     OffsetHandler + EntitiesManager + Gun + Exp03_vFinal_Task.on_step_middle / on_step_end on 288 arenas
   drive_logic.npz    LoyalWingmanBehaviorTree + KamikazeNavigator inside Exp03_vFinal_Task around one env.step (commands of step t and t+1) on 320 arenas
   level5_logic.npz   Level5_Task (six wingmen) + level5 EntitiesManager + core OffsetHandler + navigators through a whole step cycle on 256 arenas
+  level5_dumb_logic.npz  the same cycle of Level5DumbMultiObjectTask: seven scripted wingmen, 30 invader slots, its own reward (te_step_students)
   stage_logic.npz    stage02: L3Stage1.on_step_middle / on_step_end + level3 OffsetHandler / QuadcopterManager / Gun on 224 arenas;
                      stage01: PyflytL2EnviromentModifiedV2 reward / termination / replace_invader_if_close on 160 arenas
   lidar_math.npz     LidarMath binning of 1 000 body-frame vectors; add_features (closer wins) on 50 feature lists
@@ -93,6 +94,24 @@ def test_level5_logic_fixture_through_the_c_abi(golden):
     env.step_stacked(_zeros(n), terminal=False)
     c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
     assert c1 >= 900 and s1 >= 250 and c2 >= 700 and s2 >= 250, (c1, s1, c2, s2)
+    env.close()
+
+
+def test_level5_dumb_logic_fixture_through_the_c_abi(golden):
+    from dronechase_amd import default_config
+    g = golden("level5_dumb_logic.npz")
+    cfg = T.config5_dumb(default_config, g)
+    env = _gpu(cfg)
+    n, D = cfg.n_envs, cfg.n_drones
+    _load(env, T.build_blob_drive(g, env.state_words()))
+    out = env.step_students()
+    reward, done, info = (x.cpu().numpy() for x in out[-3:])
+    after = _state(env, n, D)
+    assert T.compare(g, reward, done, info, after) == n >= 200
+    c1, s1 = T.compare_commands(g, after, 1)
+    env.step_students()
+    c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
+    assert c1 >= 1000 and s1 >= 250 and c2 >= 800 and s2 >= 250, (c1, s1, c2, s2)
     env.close()
 
 
