@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--task", default="stage03", help="stage01 | stage02 | exp02 | stage03 (= exp03) | exp04 | level5 (stacked observation) | exp05 (ally observed + driven by the caller every step)")
+    ap.add_argument("--task", default="stage03", help="stage01 | stage02 | exp02 | stage03 (= exp03) | exp04 | level5 (stacked observation) | exp05 (ally observed + driven by the caller every step) | evaluation | level5_2bt")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--n-invaders", type=int, default=0, help="override I (stage02 with 8 invaders: --n-invaders 8)")
     ap.add_argument("--no-noise", action="store_true", help="motor noise off (parity runs); default on")

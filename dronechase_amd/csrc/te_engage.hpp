@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   }
   agent_kills += agent_shots; allies_kills += ally_shots; deads += exploded;
   // process_invaders_in_origin (:656-659); commented out in Evaluation_Task.on_step_middle (evaluation_task.py:397)
-  if (!c.evaluation && valid) { killed |= org & inv_bits; A &= ~(org & inv_bits); }
+  if ((!c.evaluation || (c.evaluation & TE_EVAL_ORIGIN_RULE)) && valid) { killed |= org & inv_bits; A &= ~(org & inv_bits); }
   for (M m = killed; m; m &= m - 1) {   // Quadcopter.disarm: static body, velocities / motors / set-point zeroed
     const int so = (lowest(m) * p.Npad + env) * 4;
     stv(TE_D_ARMED, so, 0u);

@@ -768,7 +768,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
   const int deads = v.egi(TE_E_DEADS) + exploded;
   v.esi(TE_E_AGENT_KILLS, agent_kills); v.esi(TE_E_ALLIES_KILLS, allies_kills); v.esi(TE_E_DEADS, deads);
   // process_invaders_in_origin (:656-659); commented out in Evaluation_Task.on_step_middle (evaluation_task.py:397)
-  if (!c.evaluation)
+  if (!c.evaluation || (c.evaluation & TE_EVAL_ORIGIN_RULE))
     for (uint32_t m = org & inv_bits; m; m &= m - 1) kill(__ffs(m) - 1);
 
   TE_LSTAMP(9);

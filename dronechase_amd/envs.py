@@ -183,5 +183,38 @@ class Level5DumbMultiObs(_SingleEnv):  # threatsense/level5/level5_dumb_multiobs
         return np.zeros(1, np.float32), float(reward[0]), bool(done[0]), False, info
 
 
-ENV_TASKS = {cls: cls.TASK for cls in (Level5DumbMultiObs, Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment, EvaluationEnvironment,
+class Level52BTEvaluationEnvironment(_SingleEnv):  # threatsense/level5/level5_eval_2bt_environment.py:12
+    """Two behaviour-tree wingmen against the 30-slot invader table (Level52BTEvaluationTask).  As in the reference `reset` and `step`
+    return an EMPTY observation (`{}`: level5_eval_2bt_environment.py:53-56,75), reward 0.0, and the info of
+    Level52BTEvaluationTask.compute_info (level5_2bt_evaluation_task.py:470-477): `kills_per_drone` = {drone id: {"name", "type": "BT",
+    "kills"}} (ids 0 and 1 here: the reference's are PyBullet body ids), `deads`, `current_wave`."""
+    TASK = "level5_2bt"
+    NAMES = ("Ally1", "Ally2")   # spawn_pursuer_squad (level5_2bt_evaluation_task.py:541-547): every pursuer is an "Ally{i}"
+
+    def __init__(self, GUI: bool = False, rl_frequency: int = 15, dome_radius: Optional[float] = None, **overrides):
+        super().__init__(dome_radius, rl_frequency, GUI, **overrides)
+        from . import spaces as S
+        self.observation_space = S.Box(0, 1, shape=(1,), dtype=np.float32)      # level5_eval_2bt_environment.py:27-29
+        self._zero = None
+
+    def _info(self):
+        rows = self._b.wingman_info()[0].cpu().numpy()     # (kills, alive, munition, wave, step) per wingman
+        deads = int(self._b.get_state()[self._b.cfg.n_drones * K.DRONE_WORDS + K.E["DEADS"]].item())
+        return {"kills_per_drone": {p: {"name": self.NAMES[p], "type": "BT", "kills": int(rows[p, 0])} for p in range(rows.shape[0])},
+                "deads": deads, "current_wave": int(rows[0, 3])}
+
+    def reset(self, seed=0, options=None):
+        self._b.reset()
+        return {}, self._info()
+
+    def step(self, action=None):
+        import torch
+
+        if self._zero is None:   # the action is not used (level5_eval_2bt_environment.py:41-58): both wingmen obey the tree
+            self._zero = torch.zeros((1, 4), dtype=torch.float32, device=self._b.device)
+        done = self._b.step(self._zero, terminal=False)[4]
+        return {}, 0.0, bool(done[0].item()), False, self._info()
+
+
+ENV_TASKS = {cls: cls.TASK for cls in (Level5DumbMultiObs, Level52BTEvaluationEnvironment, Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment, EvaluationEnvironment,
                                        PyflytL2EnviromentModifiedV2, PyflytL3EnviromentV2, Level5Environment)}

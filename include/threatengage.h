@@ -48,6 +48,11 @@ enum {
                           collector's environment — 7 wingmen ALL flown by the behaviour tree (the agent too, :256-266), 30 invader slots
                           of which min(4 + round, 30) are armed in a round (:173-184), 26 rounds, its own reward (:452-553) and
                           termination (:555-612); the observation is the stacked one of EVERY armed wingman (te_step_students) */
+  TE_TASK_LEVEL5_2BT = 10, /* threatsense/level5/level5_eval_2bt_environment.py + tasks/level5_2bt_evaluation_task.py: two wingmen, both flown by
+                          the behaviour tree (:256-261), against the 30-slot invader table of the level5 fusion tasks (5 in round 1, one more
+                          per round, 26 rounds); Evaluation_Task-style rules (cfg.evaluation = TE_EVAL_ON | TE_EVAL_ORIGIN_RULE): reward 0
+                          (:421-428), a fixed limit of 1 300 steps (:111), kills counted per wingman (:127-134,408-409; te_wingman_info);
+                          the environment returns no observation (level5_eval_2bt_environment.py:27-33,53-56) */
   TE_TASK_EVALUATION = 8 /* level4/evaluation_environment.py + tasks/evaluation_task.py with behaviour-tree drivers only
                           (apps/threatengage_runner/stage03/experiments/01/evaluation_exp01_1bt_app_ready.py): cfg.evaluation = 1,
                           n_pursuers = number of drivers (default 1) */
@@ -56,6 +61,7 @@ enum {
 /* ally (pursuer slots >= 1) policy: nobody (the set-point persists), LoyalWingmanBehaviorTree, drive([0,0,0,1]) every
  * step (exp04), or the caller through te_set_ally_actions (exp05; n_pursuers must be 2, exp05_vFinal_task.py:103) */
 enum { TE_ALLY_NONE = 0, TE_ALLY_BT = 1, TE_ALLY_FROZEN = 2, TE_ALLY_EXTERNAL = 3 };
+enum { TE_EVAL_ON = 1, TE_EVAL_ORIGIN_RULE = 2 };   /* te_config.evaluation, bits 0 and 1 */
 
 /* kamikaze FSM states (core/entities/navigators/loitering_munition_navigator_air_combat_only.py:138-246) */
 enum { TE_NAV_WAIT = 0, TE_NAV_COLLIDE_WINGMAN = 1, TE_NAV_COLLIDE_BUILDING = 2 };
@@ -153,13 +159,15 @@ typedef struct te_config {
   int32_t kamikaze_cone_check; /* 0: air-combat-only navigator (_is_building_path_clear == False, used by every
                                   vFinal task); 1: cone test of loitering_munition_navigator.py:78-87 */
   int32_t stacked_obs;    /* 1: keep the per-wingman snapshot ring and serve te_step_stacked (level5) */
-  int32_t evaluation;     /* 1: Evaluation_Task rules (tasks/evaluation_task.py): EVERY pursuer is flown by the behaviour tree
+  int32_t evaluation;     /* bit 0 (TE_EVAL_ON) = 1: Evaluation_Task rules (tasks/evaluation_task.py): EVERY pursuer is flown by the behaviour tree
                              (drivers of type "bt", :257-275,655-668; te_step's actions are ignored), reward 0 (:508-515), no
                              invaders-in-origin rule (:397), termination = time limit only if max_step > 0 (TIME_IS_LIMITED,
                              :519-524), all rounds over, anybody outside the dome, all pursuers destroyed (:526-551); kills are
                              counted per wingman (TE_D_KILLS) for te_wingman_info.  Bits 8.. : mask of the pursuers whose driver
                              is the CALLER's instead of the behaviour tree (drivers of type "nn", :264-268): bit 8 + p set =
-                             pursuer p is observed with te_observe_wingman and commanded with te_set_wingman_actions */
+                             pursuer p is observed with te_observe_wingman and commanded with te_set_wingman_actions 
+                             Bit 1 (TE_EVAL_ORIGIN_RULE): invaders that reach the origin are still removed (Level52BTEvaluationTask.on_step_middle,
+                             level5_2bt_evaluation_task.py:328; Evaluation_Task has that call commented out). */
   int32_t ground_contact; /* 1: ground plane (OPT-IN, off in every preset; parity unpinned): the reference loads plane.urdf at
                              z = -6 (entities_manager.py:120-124, immovable_structures.py:123-135); a drone whose hull bottom
                              reaches it stops there: inelastic normal contact (Bullet's default restitution 0) and Coulomb

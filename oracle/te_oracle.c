@@ -1215,7 +1215,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
   }
   er->agent_kills += agent_shots; er->allies_kills += ally_shots; er->deads += exploded;
   /* process_invaders_in_origin (:656-659; offsets_handler.py:341-348); commented out in Evaluation_Task (evaluation_task.py:397) */
-  for (int j = P; j < D && !c->evaluation; ++j) {
+  for (int j = P; j < D && (!c->evaluation || (c->evaluation & TE_EVAL_ORIGIN_RULE)); ++j) { /* ... and kept by Level52BTEvaluationTask (level5_2bt_evaluation_task.py:328) */
     if (!((S >> j) & 1u)) continue;
     real n = norm3(dr[j].obs_pos);
     note_state_margin(mg, n, (real)c->origin_range);

@@ -104,6 +104,12 @@ def config5_dumb(default_config, g, **extra):
                           dome_radius=float(g["dome"]), **extra)
 
 
+def config5_2bt(default_config, g, **extra):
+    n = len(g["step"])
+    return default_config("level5_2bt", n_envs=n, substeps=0, observe_lag=0, motor_noise=0, auto_reset=0, seed=int(g["seed"]),
+                          dome_radius=float(g["dome"]), **extra)
+
+
 def compare_commands(g, after: Blob, which: int, still_armed=None, atol=2e-6):
     """Set-point words and invader states after product step `which` (1: the commands of step t, 2: of step t+1) against the reference's
     navigators.  Only drones that are still armed when the state is read can be compared (disarm clears the set-point), and update #2 only

@@ -38,6 +38,9 @@ KINDS = {
     # Level5DumbMultiObjectTask (level5_dumb_multiobject_task.py:87-103): 6 + 1 wingmen ALL flown by the behaviour tree (:258-263), 5 invaders in round 1,
     # one more per round up to 30, munition = all the invaders of an episode, its own reward (:452-559), the agent's death does not end the episode
     "level5_dumb": ("level5_dumb_multiobject_task", "Level5DumbMultiObjectTask", 7, 30, 26, 455, lambda r: min(r - 1 + 5, 30), True, "level5_dumb_logic.npz"),
+    # Level52BTEvaluationTask (level5_2bt_evaluation_task.py:82-134): two wingmen, both scripted, the same invader table, reward 0, a fixed 1 300-step
+    # limit, kills counted per wingman (kills_per_drone) instead of agent / allies
+    "level5_2bt": ("level5_2bt_evaluation_task", "Level52BTEvaluationTask", 2, 30, 26, 455, lambda r: min(r - 1 + 5, 30), True, "level5_2bt_logic.npz"),
 }
 KIND = "level5"
 
@@ -64,6 +67,7 @@ def load_reference():
             self._inertial = {"position": np.zeros(3), "velocity": np.zeros(3), "attitude": np.zeros(3), "angular_rate": np.zeros(3)}
             self.formation_position = np.zeros(3)
             self.last_drive = None
+            self.quadcopter_name = f"drone{id_}"
 
         armed = property(lambda self: self._armed)
         inertial_data = property(lambda self: self._inertial)
@@ -123,6 +127,7 @@ def make_arenas(rng, n):
         if rng.rand() < 0.06: a["armed"][1:P] = 0           # the agent alone: identify_closest_ally == -1
         a["armed"][0] = 1                       # the agent's death ends the episode: it is armed at the start of every step
         if KINDS[KIND][7] and rng.rand() < 0.08: a["armed"][0] = 0   # ... except where the task goes on without it
+        if not a["armed"][:P].any(): a["armed"][0] = 1               # (an episode with no pursuer left has ended)
         for p in range(P):
             a["pos"][p] = rng.uniform(-3, 3, 3) * [1, 1, 0.5] + [0, 0, 1.5]
         if rng.rand() < 0.15: a["pos"][1] = a["pos"][0] + rng.uniform(-0.5, 0.5, 3)
@@ -148,6 +153,7 @@ def make_arenas(rng, n):
         a["munition"] = rng.choice([0, 1, 5, KINDS[KIND][5]], P).astype(np.int32)
         a["step"] = int(rng.choice([5, 61, 150, 299, 300, 301, 420]))
         a["max_step"] = int(rng.choice([300, 400, 500]))
+        if KIND == "level5_2bt": a["step"], a["max_step"] = int(rng.choice([5, 61, 150, 640, 1299, 1300, 1301, 1420])), 1300
         a["last_fired"] = np.array([rng.choice([-60, a["step"] - 3, a["step"] - 60, a["step"] - 75]) for _ in range(P)], np.int32)
         a["last_dist"] = float(rng.uniform(0, 10))
         a["nav"] = rng.randint(0, 3, I)
@@ -228,7 +234,10 @@ def main(kind="level5", n=256):
             task.kamikaze_navigator.state_registry[drones[P + j].id] = state_of[STATES[a["nav"][j]]]()
         task.MAX_STEP = int(a["max_step"]); task.current_round = int(a["round"])
         task.last_closest_distance = float(a["last_dist"])
-        task.agent_kills, task.allies_kills, task.deads = (int(x) for x in a["kills"])
+        if hasattr(task, "kills_per_drone"):      # Level52BTEvaluationTask counts per wingman
+            task.kills_per_drone[100]["kills"], task.kills_per_drone[101]["kills"], task.deads = (int(x) for x in a["kills"])
+        else:
+            task.agent_kills, task.allies_kills, task.deads = (int(x) for x in a["kills"])
         task.offset_handler.on_episode_start()
         step = int(a["step"])
         G.broadcast_step(hub, step - 1)
@@ -257,6 +266,10 @@ def main(kind="level5", n=256):
         reward, done = task.on_step_middle()
         assert not Draw.queue
         info = task.compute_info()
+        if "kills_per_drone" in info:             # the product's info row is (kills of slot 0, kills of the others, deads, wave)
+            kp = info["kills_per_drone"]
+            info = dict(info, agent_kills=kp[100]["kills"], allies_kills=kp[101]["kills"])
+            task.agent_kills, task.allies_kills = info["agent_kills"], info["allies_kills"]
         round_before = task.current_round
         mun_after = np.array([drones[p].gun.munition for p in range(P)], np.int32)
         lf_after = np.array([int(drones[p].gun.last_fired_step) for p in range(P)], np.int32)
@@ -272,7 +285,7 @@ def main(kind="level5", n=256):
             nav2 = np.array([STATES.index(task.kamikaze_navigator.fetch_state(drones[P + j]).name) if armed_after[P + j] else -1 for j in range(I)], np.int32)
         for k, v in dict(armed=a["armed"], pos=a["pos"], vel=a["vel"], munition=a["munition"], last_fired=a["last_fired"], step=step, max_step=a["max_step"],
                          round=a["round"], last_dist=a["last_dist"], kills=a["kills"], nav=a["nav"], formation=a["formation"], cmd1=cmd1, nav1=nav1,
-                         counts=np.array(seen["c"], np.int32), reward=float(reward), done=int(bool(done)),
+                         counts=np.array(seen["c"] if len(seen["c"]) else (0, 0, 0, 0, 0), np.int32), reward=float(reward), done=int(bool(done)),
                          info=[info["agent_kills"], info["allies_kills"], info["deads"], info["current_wave"]], armed_mid=seen["armed_mid"],
                          armed_after=armed_after, munition_after=mun_after, last_fired_after=lf_after, max_step_after=task.MAX_STEP,
                          kills_after=[task.agent_kills, task.allies_kills, task.deads], last_dist_after=task.last_closest_distance,

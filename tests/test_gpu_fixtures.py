@@ -5,6 +5,7 @@ not with the oracle: te_set_state -> te_step / te_observe -> outputs + te_get_st
   drive_logic.npz    LoyalWingmanBehaviorTree + KamikazeNavigator inside Exp03_vFinal_Task around one env.step (commands of step t and t+1) on 320 arenas
   level5_logic.npz   Level5_Task (six wingmen) + level5 EntitiesManager + core OffsetHandler + navigators through a whole step cycle on 256 arenas
   level5_dumb_logic.npz  the same cycle of Level5DumbMultiObjectTask: seven scripted wingmen, 30 invader slots, its own reward (te_step_students)
+  level5_2bt_logic.npz   ... and of Level52BTEvaluationTask: two scripted wingmen, reward 0, fixed limit, kills per wingman (te_step + te_wingman_info)
   stage_logic.npz    stage02: L3Stage1.on_step_middle / on_step_end + level3 OffsetHandler / QuadcopterManager / Gun on 224 arenas;
                      stage01: PyflytL2EnviromentModifiedV2 reward / termination / replace_invader_if_close on 160 arenas
   lidar_math.npz     LidarMath binning of 1 000 body-frame vectors; add_features (closer wins) on 50 feature lists
@@ -112,6 +113,28 @@ def test_level5_dumb_logic_fixture_through_the_c_abi(golden):
     env.step_students()
     c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
     assert c1 >= 1000 and s1 >= 250 and c2 >= 800 and s2 >= 250, (c1, s1, c2, s2)
+    env.close()
+
+
+def test_level5_2bt_logic_fixture_through_the_c_abi(golden):
+    """Level52BTEvaluationTask (TE_TASK_LEVEL5_2BT): two scripted wingmen, 30 invader slots, reward 0, fixed step limit, per-wingman kills."""
+    from dronechase_amd import default_config
+    g = golden("level5_2bt_logic.npz")
+    cfg = T.config5_2bt(default_config, g)
+    env = _gpu(cfg)
+    n, D = cfg.n_envs, cfg.n_drones
+    _load(env, T.build_blob_drive(g, env.state_words()))
+    out = env.step(_zeros(n), terminal=False)
+    reward, done, info = (x.cpu().numpy() for x in out[-3:])
+    after = _state(env, n, D)
+    assert T.compare(g, reward, done, info, after) == n >= 200
+    rows = env.wingman_info().cpu().numpy()                  # (kills, alive, munition, wave, step) per wingman
+    for e in range(n):
+        assert list(rows[e, :, 0]) == list(g["kills_after"][e, :2] - g["kills"][e, :2]), e
+    c1, s1 = T.compare_commands(g, after, 1)
+    env.step(_zeros(n), terminal=False)
+    c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
+    assert c1 >= 800 and s1 >= 500 and c2 >= 600 and s2 >= 500, (c1, s1, c2, s2)
     env.close()
 
 

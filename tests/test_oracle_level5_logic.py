@@ -73,3 +73,42 @@ def test_oracle_reproduces_the_reference_dumb_multiobject_step_cycle(gd, prec):
     orc.step_students()
     c2, s2 = T.compare_commands(g, Blob(orc.get_state(), n, D), 2)
     assert c1 >= 1000 and s1 >= 250 and c2 >= 800 and s2 >= 250, (c1, s1, c2, s2)
+
+
+# ---------------------------------------------------------------------------------------------------------------- Level52BTEvaluationTask
+@pytest.fixture(scope="module")
+def g2(golden):
+    return golden("level5_2bt_logic.npz")
+
+
+def test_2bt_fixture_covers_the_branches(g2):
+    g = g2
+    kills = g["kills_after"][:, :2] - g["kills"][:, :2]
+    assert (kills[:, 0] > 0).sum() >= 30 and (kills[:, 1] > 0).sum() >= 30 and (g["kills_after"][:, 2] > g["kills"][:, 2]).sum() >= 20
+    assert (g["reward"] == 0).all() and (g["max_step_after"] == 1300).all()     # no reward, a fixed limit (a hit does not extend it)
+    assert ((g["step"] > 1300) & (g["done"] == 1)).sum() >= 20 and ((g["step"] <= 1300) & (g["done"] == 0)).sum() >= 80
+    origin = (np.linalg.norm(g["pos"][:, 2:], axis=2) < 0.2) & (g["armed"][:, 2:] == 1)
+    assert origin.any(1).sum() >= 10                                            # the invaders-in-origin rule stays on in this task
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_oracle_reproduces_the_reference_2bt_evaluation_step_cycle(g2, prec):
+    from oracle import te_oracle as O
+    g = g2
+    cfg = T.config5_2bt(O.default_config, g)
+    assert (cfg.n_pursuers, cfg.n_invaders, cfg.n_rounds, cfg.munition, cfg.max_step, cfg.step_increment) == (2, 30, 26, 455, 1300, 0)
+    orc = O.OracleEnv(cfg, prec)
+    orc.set_state(T.build_blob_drive(g, orc.state_words()).w)
+    n, D = cfg.n_envs, cfg.n_drones
+    zeros = np.zeros((n, 4), np.float32)
+    out = orc.step(zeros, terminal=False)
+    reward, done, info = out[-3], out[-2], out[-1]
+    after = Blob(orc.get_state(), n, D)
+    assert T.compare(g, reward, done, info, after) == n
+    # kills_per_drone = the wingmen's own kill words (the blob started them at 0: this step's kills)
+    for e in range(n):
+        assert [after.i(e, p, "KILLS") for p in range(2)] == list(g["kills_after"][e, :2] - g["kills"][e, :2]), e
+    c1, s1 = T.compare_commands(g, after, 1)
+    orc.step(zeros, terminal=False)
+    c2, s2 = T.compare_commands(g, Blob(orc.get_state(), n, D), 2)
+    assert c1 >= 800 and s1 >= 500 and c2 >= 600 and s2 >= 500, (c1, s1, c2, s2)
