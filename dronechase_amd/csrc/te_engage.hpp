@@ -483,6 +483,15 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
       if (zone & pur_bits) penalty += 1000.0f;
       if (dist_origin > c.born_radius - 2.0f) penalty += fminf(dist_origin - (c.born_radius - 2.0f), 1000.0f);
       reward = clampf(score + bonus - penalty, -3000.0f, 3000.0f);
+    } else if (c.reward_model == TE_REWARD_L5_C1) {  // Level5C1FusionTask.compute_reward (level5_c1_fusion_task.py:448-485)
+      const int t1 = (S & one) ? tgt[0] : -1;        // the agent's OWN closest invader (:458)
+      const float d1 = t1 >= 0 ? fdist(apos, pos_of(t1)) : dist_origin;
+      const float first = last_dist == 0.0f ? d1 : last_dist;   // `last_distance` is set by the first reward of the env and never again (:467-468)
+      float r1 = d1 < first ? c.approach_bonus_gain * fnorm(V3{ag[3], ag[4], ag[5]}) : 0.0f;
+      if (agent_shots > 0) r1 += (float)agent_shots * 1000.0f;
+      if (agent_suicided > 0) r1 -= 2.0f * (float)agent_suicided * 1000.0f;
+      reward = clampf(r1, -3000.0f, 3000.0f);
+      cur_dist = first;
     } else {
     if (0.01f < last_dist - cur_dist && ready) bonus += c.approach_bonus_gain * fnorm(V3{ag[3], ag[4], ag[5]});
     const float score = ready ? -cur_dist : cur_dist * (2.0f * gs[1] - 1.0f);
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     snap_mask = mask_after_spawn(1, true);
     ste(TE_E_EPISODE, episode); ste(TE_E_STEP, 0u); ste(TE_E_MAX_STEP, (uint32_t)c.max_step); ste(TE_E_ROUND, 1u);
     ste(TE_E_AGENT_KILLS, 0u); ste(TE_E_ALLIES_KILLS, 0u); ste(TE_E_DEADS, 0u);
-    stef(TE_E_LAST_DIST, c.dome_radius);
+    if (c.reward_model != TE_REWARD_L5_C1) stef(TE_E_LAST_DIST, c.dome_radius);
 #pragma unroll
     for (int k = 0; k < 4; ++k) ste(TE_E_LAST_ACTION + k, 0u);
     ste(TE_E_SNAP_MASK, (uint32_t)snap_mask); ste(TE_E_SNAP_MASK_HI, (uint32_t)((uint64_t)snap_mask >> 32));

@@ -898,7 +898,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   // substeps == 0: env.step() without physics (the IMU is read from the state as it is, then engagement / reward / termination /
   // waves / observation as usual).  Used to replay the reference's task-logic fixtures on exactly their positions.
   if (cfg->substeps == 0 && cfg->observe_lag != 0) return fail("te_create: substeps == 0 (no physics) needs observe_lag == 0");
-  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_LEVEL5_2BT) return fail("te_create: unknown task");
+  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_LEVEL5_C1) return fail("te_create: unknown task");
   if (cfg->ground_contact && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: cfg.ground_contact is built for the level4 task family only");
   if (cfg->evaluation && (((uint32_t)cfg->evaluation >> 8) >> cfg->n_pursuers) != 0u) return fail("te_create: cfg.evaluation's driver mask names a pursuer that does not exist");
   if (cfg->evaluation && !(family_of(cfg->task) == FAM_LEVEL4 && cfg->ally_policy == TE_ALLY_BT && !cfg->stacked_obs))

@@ -383,7 +383,7 @@ template <class V> TE_DEV uint32_t level4_reset_record(const te_config& c, const
   v.esi(TE_E_EPISODE, (int)episode);
   v.esi(TE_E_STEP, 0); v.esi(TE_E_MAX_STEP, c.max_step); v.esi(TE_E_ROUND, 1);
   v.esi(TE_E_AGENT_KILLS, 0); v.esi(TE_E_ALLIES_KILLS, 0); v.esi(TE_E_DEADS, 0);
-  v.esf(TE_E_LAST_DIST, c.dome_radius);
+  if (c.reward_model != TE_REWARD_L5_C1) v.esf(TE_E_LAST_DIST, c.dome_radius);   // Level5C1FusionTask's last_distance outlives every reset
 #pragma unroll
   for (int k = 0; k < 4; ++k) v.esf(TE_E_LAST_ACTION + k, 0.0f);
   set_snap_mask(v, level4_mask_after_spawn(c, v, 1, true));

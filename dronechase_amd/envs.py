@@ -183,6 +183,19 @@ class Level5DumbMultiObs(_SingleEnv):  # threatsense/level5/level5_dumb_multiobs
         return np.zeros(1, np.float32), float(reward[0]), bool(done[0]), False, info
 
 
+class Level5C1FusionEnvironment(_SingleEnv):  # threatsense/level5/level5_c1_fusion_environment.py:7
+    """The agent and one scripted wingman against 4 -> 10 invaders, the student observation of Level5Environment, Level5C1FusionTask's
+    minimal reward; `info` is empty (level5_c1_fusion_environment.py:105-106)."""
+    TASK = "level5_c1"
+
+    def __init__(self, GUI: bool = False, rl_frequency: int = 15, dome_radius: Optional[float] = None, **overrides):
+        super().__init__(dome_radius, rl_frequency, GUI, **overrides)
+
+    def step(self, rl_action: np.ndarray):
+        obs, reward, done, truncated, _ = super().step(rl_action)
+        return obs, reward, done, truncated, {}
+
+
 class Level52BTEvaluationEnvironment(_SingleEnv):  # threatsense/level5/level5_eval_2bt_environment.py:12
     """Two behaviour-tree wingmen against the 30-slot invader table (Level52BTEvaluationTask).  As in the reference `reset` and `step`
     return an EMPTY observation (`{}`: level5_eval_2bt_environment.py:53-56,75), reward 0.0, and the info of
@@ -216,5 +229,5 @@ class Level52BTEvaluationEnvironment(_SingleEnv):  # threatsense/level5/level5_e
         return {}, 0.0, bool(done[0].item()), False, self._info()
 
 
-ENV_TASKS = {cls: cls.TASK for cls in (Level5DumbMultiObs, Level52BTEvaluationEnvironment, Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment, EvaluationEnvironment,
+ENV_TASKS = {cls: cls.TASK for cls in (Level5DumbMultiObs, Level52BTEvaluationEnvironment, Level5C1FusionEnvironment, Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment, EvaluationEnvironment,
                                        PyflytL2EnviromentModifiedV2, PyflytL3EnviromentV2, Level5Environment)}

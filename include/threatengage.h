@@ -53,6 +53,9 @@ enum {
                           per round, 26 rounds); Evaluation_Task-style rules (cfg.evaluation = TE_EVAL_ON | TE_EVAL_ORIGIN_RULE): reward 0
                           (:421-428), a fixed limit of 1 300 steps (:111), kills counted per wingman (:127-134,408-409; te_wingman_info);
                           the environment returns no observation (level5_eval_2bt_environment.py:27-33,53-56) */
+  TE_TASK_LEVEL5_C1 = 11, /* threatsense/level5/level5_c1_fusion_environment.py + tasks/level5_c1_fusion_task.py: the RL agent and ONE scripted wingman
+                          against 10 invader slots (4 in round 1, one more per round, 7 rounds; munition 49), the stacked observation of level5
+                          (te_step_stacked) and the task's minimal reward (cfg.reward_model = TE_REWARD_L5_C1) */
   TE_TASK_EVALUATION = 8 /* level4/evaluation_environment.py + tasks/evaluation_task.py with behaviour-tree drivers only
                           (apps/threatengage_runner/stage03/experiments/01/evaluation_exp01_1bt_app_ready.py): cfg.evaluation = 1,
                           n_pursuers = number of drivers (default 1) */
@@ -199,7 +202,11 @@ typedef struct te_config {
   int32_t agent_scripted;     /* 1: pursuer 0 obeys the behaviour tree like the other wingmen and te_step's actions are ignored
                                  (level5_dumb_multiobject_task.py:256-266; implied by cfg.evaluation) */
   int32_t reward_model;       /* TE_REWARD_EXP03 (0): exp03_vFinal_task.py:423-515; TE_REWARD_L5_DUMB (1): level5_dumb_multiobject_task.py:452-553
-                                 (reload-distance shaping, weighted kills / deaths, bounded border term, clipped to +-3000) */
+                                 (reload-distance shaping, weighted kills / deaths, bounded border term, clipped to +-3000) 
+                                 TE_REWARD_L5_C1 (2): Level5C1FusionTask.compute_reward (level5_c1_fusion_task.py:448-485): 10 |v| while the agent is closer to
+                                 ITS closest invader than at the FIRST reward of this te_env's env (`self.last_distance` is set once and never
+                                 again, not even by a reset: TE_E_LAST_DIST holds it, 0 = not measured yet), + 1000 per agent kill, - 2000 for
+                                 the agent's suicide, clipped to +-3000 */
   int32_t agent_death_terminates; /* 1: the episode ends when pursuer 0 is disarmed (training tasks, exp03_vFinal_task.py:556-561);
                                  0: it goes on (level5_dumb_multiobject_task.py:600-606 has the test commented out) */
   int32_t quad_preset;    /* which table te_config_default / te_quad_preset filled `quad` with: TE_QUAD_CF2X_RECALLED (0) or
@@ -209,7 +216,7 @@ typedef struct te_config {
 } te_config;
 
 enum { TE_IO_DEVICE = 0, TE_IO_HOST = 1 };
-enum { TE_REWARD_EXP03 = 0, TE_REWARD_L5_DUMB = 1 };
+enum { TE_REWARD_EXP03 = 0, TE_REWARD_L5_DUMB = 1, TE_REWARD_L5_C1 = 2 };
 /* quadrotor parameter presets (te_quad_preset).  RECALLED = PyFlyt 0.11.1's cf2x.yaml / cf2x.urdf as recorded in SURVEY.md
  * Appendix B (the default of every task); RECORDED_FIT = the same table with the smallest change that reproduces the only
  * PyBullet-made numbers in the reference tree (io_data0.h5: seven wingmen, two steps after a respawn) within its motor-noise

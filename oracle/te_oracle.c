@@ -1070,7 +1070,7 @@ static void level4_reset_env(ote_env* E, int e) {
   /* on_episode_end: init_constants / init_globals / disarm_all */
   er->step = 0; er->max_step = c->max_step; er->round = 1;
   er->agent_kills = 0; er->allies_kills = 0; er->deads = 0;
-  er->last_dist = (real)c->dome_radius;
+  if (c->reward_model != TE_REWARD_L5_C1) er->last_dist = (real)c->dome_radius; /* Level5C1FusionTask's last_distance outlives every reset */
   for (int k = 0; k < 4; ++k) er->last_action[k] = 0;
   for (int p = 0; p < c->n_pursuers; ++p) for (int k = 0; k < 4; ++k) dr[p].ext_action[k] = 0; /* exp05_vFinal_task.py:139 (init_globals) */
   for (int i = 0; i < E->D; ++i) disarm(&dr[i]);
@@ -1266,6 +1266,20 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
       er->last_dist = cur;
       real total = score + bonus - penalty;
       score = clampr(total, (real)-3 * MAXR, (real)3 * MAXR); bonus = 0; penalty = 0;
+    } else if (c->reward_model == TE_REWARD_L5_C1) { /* Level5C1FusionTask.compute_reward (level5_c1_fusion_task.py:448-485) */
+      /* the agent's OWN closest invader (:458), not the closest ally's */
+      int t1 = -1; real bd = 0;
+      for (int j = P; j < D; ++j)
+        if ((S >> j) & 1u) { real d = dist3(ag->obs_pos, dr[j].obs_pos); if (t1 < 0 || d < bd) { t1 = j; bd = d; } }
+      if (!((S >> 0) & 1u)) t1 = -1;
+      real d1 = t1 >= 0 ? bd : norm3(ag->obs_pos);
+      if (er->last_dist == (real)0) er->last_dist = d1; /* `self.last_distance = distance if not hasattr(...) else self.last_distance` (:467-468): set once */
+      note_margin(&mg[0], d1, er->last_dist);
+      real r1 = 0;
+      if (d1 < er->last_dist) r1 += (real)c->approach_bonus_gain * norm3(ag->obs_vel);
+      if (agent_shots > 0) r1 += (real)agent_shots * MAXR;
+      if (agent_suicided > 0) r1 -= (real)2 * (real)agent_suicided * MAXR;
+      score = clampr(r1, (real)-3 * MAXR, (real)3 * MAXR); bonus = 0; penalty = 0;
     } else {
     note_margin(&mg[0], er->last_dist - cur, (real)0.01);
     if ((real)0.01 < er->last_dist - cur && ready) bonus += (real)c->approach_bonus_gain * norm3(ag->obs_vel);

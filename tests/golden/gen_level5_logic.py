@@ -40,6 +40,9 @@ KINDS = {
     "level5_dumb": ("level5_dumb_multiobject_task", "Level5DumbMultiObjectTask", 7, 30, 26, 455, lambda r: min(r - 1 + 5, 30), True, "level5_dumb_logic.npz"),
     # Level52BTEvaluationTask (level5_2bt_evaluation_task.py:82-134): two wingmen, both scripted, the same invader table, reward 0, a fixed 1 300-step
     # limit, kills counted per wingman (kills_per_drone) instead of agent / allies
+    # Level5C1FusionTask (level5_c1_fusion_task.py:82-111,448-485): the agent + one scripted wingman, 10 invader slots (4 + 1 per round, 7 rounds), the
+    # minimal reward whose `last_distance` is set by the first call and never again
+    "level5_c1": ("level5_c1_fusion_task", "Level5C1FusionTask", 2, 10, 7, 49, lambda r: min(r - 1 + 4, 10), False, "level5_c1_logic.npz"),
     "level5_2bt": ("level5_2bt_evaluation_task", "Level52BTEvaluationTask", 2, 30, 26, 455, lambda r: min(r - 1 + 5, 30), True, "level5_2bt_logic.npz"),
 }
 KIND = "level5"
@@ -234,6 +237,9 @@ def main(kind="level5", n=256):
             task.kamikaze_navigator.state_registry[drones[P + j].id] = state_of[STATES[a["nav"][j]]]()
         task.MAX_STEP = int(a["max_step"]); task.current_round = int(a["round"])
         task.last_closest_distance = float(a["last_dist"])
+        if kind == "level5_c1":                    # compute_reward keeps `self.last_distance`: absent until the first call (arena value 0), then frozen
+            if rng.rand() < 0.15: a["last_dist"] = 0.0
+            else: task.last_distance = float(a["last_dist"])
         if hasattr(task, "kills_per_drone"):      # Level52BTEvaluationTask counts per wingman
             task.kills_per_drone[100]["kills"], task.kills_per_drone[101]["kills"], task.deads = (int(x) for x in a["kills"])
         else:
@@ -288,7 +294,8 @@ def main(kind="level5", n=256):
                          counts=np.array(seen["c"] if len(seen["c"]) else (0, 0, 0, 0, 0), np.int32), reward=float(reward), done=int(bool(done)),
                          info=[info["agent_kills"], info["allies_kills"], info["deads"], info["current_wave"]], armed_mid=seen["armed_mid"],
                          armed_after=armed_after, munition_after=mun_after, last_fired_after=lf_after, max_step_after=task.MAX_STEP,
-                         kills_after=[task.agent_kills, task.allies_kills, task.deads], last_dist_after=task.last_closest_distance,
+                         kills_after=[task.agent_kills, task.allies_kills, task.deads],
+                         last_dist_after=task.last_distance if kind == "level5_c1" else task.last_closest_distance,
                          round_after=task.current_round, shots_fired=fired, cmd2=cmd2, nav2=nav2, comparable=comparable,
                          closest_ally=ca_slot, target=slot_of(tgt) if tgt != -1 else -1).items():
             rec[k].append(v)

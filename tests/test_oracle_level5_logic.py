@@ -112,3 +112,56 @@ def test_oracle_reproduces_the_reference_2bt_evaluation_step_cycle(g2, prec):
     orc.step(zeros, terminal=False)
     c2, s2 = T.compare_commands(g, Blob(orc.get_state(), n, D), 2)
     assert c1 >= 800 and s1 >= 500 and c2 >= 600 and s2 >= 500, (c1, s1, c2, s2)
+
+
+# ---------------------------------------------------------------------------------------------------------------- Level5C1FusionTask
+@pytest.fixture(scope="module")
+def gc(golden):
+    return golden("level5_c1_logic.npz")
+
+
+def test_c1_fixture_covers_the_branches(gc):
+    g = gc
+    c = g["counts"]
+    assert (c[:, 0] > 0).sum() >= 40 and (c[:, 4] > 0).sum() >= 15          # agent kills (+1000 each), agent suicides (-2000)
+    assert (g["last_dist"] == 0).sum() >= 20                                # the first reward of an env: last_distance is born here
+    d_agent = np.array([min([np.linalg.norm(g["pos"][e, 0] - g["pos"][e, 2 + j]) for j in range(10) if g["armed"][e, 2 + j]] or [np.linalg.norm(g["pos"][e, 0])])
+                        for e in range(len(c))])
+    closer = (d_agent < g["last_dist"]) & (g["last_dist"] > 0)
+    assert closer.sum() >= 50 and (~closer).sum() >= 50                      # the 10 |v| term on and off
+    assert np.abs(g["reward"]).max() <= 3000.0 + 1e-9
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_oracle_reproduces_the_reference_c1_fusion_step_cycle(gc, prec):
+    from oracle import te_oracle as O
+    g = gc
+    cfg = T.config5_c1(O.default_config, g)
+    assert (cfg.n_pursuers, cfg.n_invaders, cfg.n_rounds, cfg.munition, cfg.initial_invaders, cfg.stacked_obs) == (2, 10, 7, 49, 4, 1)
+    orc = O.OracleEnv(cfg, prec)
+    orc.set_state(T.build_blob_drive(g, orc.state_words()).w)
+    n, D = cfg.n_envs, cfg.n_drones
+    zeros = np.zeros((n, 4), np.float32)
+    out = orc.step_stacked(zeros, terminal=False)
+    after = Blob(orc.get_state(), n, D)
+    assert T.compare(g, out[-3], out[-2], out[-1], after) == n
+    c1, s1 = T.compare_commands(g, after, 1)
+    orc.step_stacked(zeros, terminal=False)
+    c2, s2 = T.compare_commands(g, Blob(orc.get_state(), n, D), 2)
+    assert c1 >= 300 and s1 >= 250 and c2 >= 250 and s2 >= 200, (c1, s1, c2, s2)
+
+
+def test_c1_last_distance_outlives_a_reset(gc):
+    """`self.last_distance` is an attribute the task never clears (init_globals does not know it): TE_E_LAST_DIST keeps it across te_reset."""
+    from oracle import te_oracle as O
+    cfg = O.default_config("level5_c1", n_envs=4, motor_noise=0, seed=3)
+    orc = O.OracleEnv(cfg, "f64")
+    orc.reset()
+    assert all(Blob(orc.get_state(), 4, cfg.n_drones).ef(e, "LAST_DIST")[0] == 0.0 for e in range(4))      # not measured yet
+    orc.step_stacked(np.zeros((4, 4), np.float32), terminal=False)
+    first = [float(Blob(orc.get_state(), 4, cfg.n_drones).ef(e, "LAST_DIST")[0]) for e in range(4)]
+    assert all(f > 0 for f in first)
+    for _ in range(3):
+        orc.step_stacked(np.zeros((4, 4), np.float32), terminal=False)
+    orc.reset()
+    assert [float(Blob(orc.get_state(), 4, cfg.n_drones).ef(e, "LAST_DIST")[0]) for e in range(4)] == first
