@@ -86,8 +86,8 @@ class BatchedEnv:
             if mask.numel() != self.N:
                 raise ValueError("mask must have n_envs entries")
         _lib.check(self.L.te_reset(self._h, self._p(mask), self._stream()), "te_reset")
-        if self.D > 32:   # Level5DumbMultiObs (37 drones): the observation comes out of step_students
-            return None
+        if self.D > 32:   # te_observe serves 32 drones: Level5DumbMultiObs (37, all scripted) observes through step_students, Level5FusionEnvironment (36) through observe_stacked
+            return None if (self.cfg.agent_scripted or self.cfg.evaluation) else self.observe_stacked()
         return self.observe()
 
     def _obs_out(self, out):

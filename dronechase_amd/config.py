@@ -9,10 +9,10 @@ import ctypes as C
 
 TE_ABI_VERSION = 5
 
-TASK_STAGE01, TASK_STAGE02, TASK_EXP02, TASK_EXP03, TASK_EXP04, TASK_LEVEL5, TASK_EXP05, TASK_EVALUATION, TASK_LEVEL5_DUMB, TASK_LEVEL5_2BT, TASK_LEVEL5_C1 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+TASK_STAGE01, TASK_STAGE02, TASK_EXP02, TASK_EXP03, TASK_EXP04, TASK_LEVEL5, TASK_EXP05, TASK_EVALUATION, TASK_LEVEL5_DUMB, TASK_LEVEL5_2BT, TASK_LEVEL5_C1, TASK_LEVEL5_FUSION = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 TASKS = {"stage01": TASK_STAGE01, "stage02": TASK_STAGE02, "exp02": TASK_EXP02, "exp03": TASK_EXP03,
          "stage03": TASK_EXP03, "exp04": TASK_EXP04, "level5": TASK_LEVEL5, "exp05": TASK_EXP05, "evaluation": TASK_EVALUATION,
-         "level5_dumb": TASK_LEVEL5_DUMB, "level5_2bt": TASK_LEVEL5_2BT, "level5_c1": TASK_LEVEL5_C1}
+         "level5_dumb": TASK_LEVEL5_DUMB, "level5_2bt": TASK_LEVEL5_2BT, "level5_c1": TASK_LEVEL5_C1, "level5_fusion": TASK_LEVEL5_FUSION}
 REWARD_EXP03, REWARD_L5_DUMB, REWARD_L5_C1 = 0, 1, 2
 EVAL_ON, EVAL_ORIGIN_RULE = 1, 2
 ALLY_NONE, ALLY_BT, ALLY_FROZEN, ALLY_EXTERNAL = 0, 1, 2, 3

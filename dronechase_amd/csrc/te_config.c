@@ -158,6 +158,18 @@ TE_API int te_config_default(te_config* c, int32_t task) {
       c->stacked_obs = 1; c->agent_scripted = 1; c->reward_model = TE_REWARD_L5_DUMB; c->agent_death_terminates = 0;
       break;
     }
+    case TE_TASK_LEVEL5_FUSION: { /* level5_fusion_task.py:81-112 */
+      const int initial = 5, per_round = 5, max_invaders = 30;
+      c->n_pursuers = 5 + 1; c->n_invaders = max_invaders;
+      c->initial_invaders = initial; c->invaders_per_round = per_round;
+      c->n_rounds = (int)ceil((double)(max_invaders - initial) / per_round + 1.0);       /* 6 */
+      c->munition = (initial + max_invaders) * c->n_rounds / 2;                          /* 105 */
+      c->dome_radius = 20.0f; c->lidar_radius = 40.0f;
+      c->max_step = 300; c->pursuer_spawn_radius = 2.0f;
+      c->ally_policy = TE_ALLY_BT; c->approach_bonus_gain = 1.0f;
+      c->stacked_obs = 1; c->reward_model = TE_REWARD_L5_DUMB;
+      break;
+    }
     case TE_TASK_LEVEL5_C1: { /* level5_c1_fusion_task.py:82-111 */
       const int initial = 4, per_round = 1, max_invaders = 10;
       c->n_pursuers = 1 + 1; c->n_invaders = max_invaders;

@@ -898,7 +898,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   // substeps == 0: env.step() without physics (the IMU is read from the state as it is, then engagement / reward / termination /
   // waves / observation as usual).  Used to replay the reference's task-logic fixtures on exactly their positions.
   if (cfg->substeps == 0 && cfg->observe_lag != 0) return fail("te_create: substeps == 0 (no physics) needs observe_lag == 0");
-  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_LEVEL5_C1) return fail("te_create: unknown task");
+  if (cfg->task < TE_TASK_STAGE01 || cfg->task > TE_TASK_LEVEL5_FUSION) return fail("te_create: unknown task");
   if (cfg->ground_contact && family_of(cfg->task) != FAM_LEVEL4) return fail("te_create: cfg.ground_contact is built for the level4 task family only");
   if (cfg->evaluation && (((uint32_t)cfg->evaluation >> 8) >> cfg->n_pursuers) != 0u) return fail("te_create: cfg.evaluation's driver mask names a pursuer that does not exist");
   if (cfg->evaluation && !(family_of(cfg->task) == FAM_LEVEL4 && cfg->ally_policy == TE_ALLY_BT && !cfg->stacked_obs))
@@ -947,8 +947,8 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   } else if (e->family == FAM_STAGE01) e->engage_regs = 4;
   if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "lds")) e->engage_regs = 0; }
   const bool regs_l4 = e->engage_regs == 1 || e->engage_regs == 2 || e->engage_regs == 5;
-  if (D > kMaxD && !(regs_l4 && cfg->stacked_obs && (cfg->agent_scripted || cfg->evaluation)))
-    return bail("te_create: more than 32 drones per env are served for the all-scripted level5 tasks only (te_step_students: stacked_obs + agent_scripted, P <= 7, P + I <= 37)");
+  if (D > kMaxD && !(regs_l4 && cfg->stacked_obs))
+    return bail("te_create: more than 32 drones per env are served for the stacked-observation tasks only (te_step_stacked / te_step_students: stacked_obs, P <= 7, P + I <= 37)");
   if ((cfg->agent_scripted || cfg->reward_model != TE_REWARD_EXP03 || !cfg->agent_death_terminates || cfg->initial_invaders != 1 || cfg->invaders_per_round != 1) && !regs_l4)
     return bail("te_create: agent_scripted / reward_model / agent_death_terminates / the round rule are built into engage_kernel: the level4 task family with P <= 7 and P + I <= 37");
   if (cfg->drone_contact && !(e->engage_regs == 1 || e->engage_regs == 2))
@@ -1164,7 +1164,7 @@ __attribute__((visibility("default"))) int te_observe(te_env* e, float* obs_lida
 }
 static int observe_device(te_env* e, float* obs_lidar, float* obs_inertial, float* obs_last_action, void* stream) {
   if (!e) return fail("te_observe: null env");
-  if (e->p.D > kMaxD) return fail("te_observe: more than 32 drones per env: the observation comes out of te_step_students");
+  if (e->p.D > kMaxD) return fail("te_observe: more than 32 drones per env: the observation comes out of te_observe_stacked / te_step_stacked (or te_step_students)");
   if ((obs_lidar && ((uintptr_t)obs_lidar & 15)) || (obs_last_action && ((uintptr_t)obs_last_action & 15)))
     return fail("te_observe: obs_lidar and obs_last_action must be 16-byte aligned");
   DeviceGuard guard(e->device);
@@ -1360,11 +1360,26 @@ __attribute__((visibility("default"))) int te_step_students(te_env* e, float* st
   return 0;
 }
 
+// te_observe_stacked beyond 32 drones per env: the agent's inertial row (normalize_inertial_data + gun state) and last action, one lane per env
+__global__ __launch_bounds__(256) void agent_rows_kernel(Params p, float* __restrict__ inertial, float* __restrict__ last_action) {
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env >= p.N) return;
+  const GView v{p.dstate, p.estate, p.D, p.Npad, env, p.cfg.n_pursuers};
+  if (inertial) {
+    float in[TE_OBS_INERTIAL_WORDS];
+    inertial_obs(p.cfg, v, v.egi(TE_E_STEP), in, 0);
+#pragma unroll
+    for (int k = 0; k < TE_OBS_INERTIAL_WORDS; ++k) inertial[(size_t)env * TE_OBS_INERTIAL_WORDS + k] = in[k];
+  }
+  if (last_action)
+    reinterpret_cast<float4*>(last_action)[env] = make_float4(v.egf(TE_E_LAST_ACTION), v.egf(TE_E_LAST_ACTION + 1), v.egf(TE_E_LAST_ACTION + 2), v.egf(TE_E_LAST_ACTION + 3));
+}
+
 __attribute__((visibility("default"))) int te_observe_stacked(te_env* e, float* obs_stacked, uint8_t* obs_mask, float* obs_inertial,
                                                               float* obs_last_action, void* stream) {
   if (!e) return fail("te_observe_stacked: null env");
   if (!e->p.ring) return fail("te_observe_stacked: this te_env was created without cfg.stacked_obs");
-  if (e->p.D > kMaxD) return fail("te_observe_stacked: more than 32 drones per env: the observation comes out of te_step_students");
+  if (e->p.D > kMaxD && all_scripted(e->p.cfg)) return fail("te_observe_stacked: an all-scripted task with more than 32 drones per env: the observation comes out of te_step_students");
   if (!obs_stacked || !obs_mask || ((uintptr_t)obs_stacked & 15)) return fail("te_observe_stacked: obs_stacked (16-byte aligned) and obs_mask are required");
   DeviceGuard guard(e->device);
   hipStream_t st = (hipStream_t)stream;
@@ -1372,7 +1387,11 @@ __attribute__((visibility("default"))) int te_observe_stacked(te_env* e, float* 
   const int blocks = (p.N + kEPB - 1) / kEPB;
   hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, obs_stacked, (size_t)p.N * TE_OBS_STACKED_WORDS);
   hipLaunchKernelGGL(snapshot_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(observe_kernel, dim3(blocks), dim3(256), e->lds_bytes, st, p, ObsOut{nullptr, obs_inertial, obs_last_action});
+  if (p.D > kMaxD) {  // Level5FusionTask (36 drones): observe_kernel stages at most 32 slots; the two rows need none of them
+    if (obs_inertial || obs_last_action) hipLaunchKernelGGL(agent_rows_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, p, obs_inertial, obs_last_action);
+  } else {
+    hipLaunchKernelGGL(observe_kernel, dim3(blocks), dim3(256), e->lds_bytes, st, p, ObsOut{nullptr, obs_inertial, obs_last_action});
+  }
   StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 0, 0, 1};
   hipLaunchKernelGGL(stacked_kernel, dim3(blocks), dim3(kStackThreads), e->stack_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
   TE_HIP(hipGetLastError());

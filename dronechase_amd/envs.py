@@ -196,6 +196,14 @@ class Level5C1FusionEnvironment(_SingleEnv):  # threatsense/level5/level5_c1_fus
         return obs, reward, done, truncated, {}
 
 
+class Level5FusionEnvironment(_SingleEnv):  # threatsense/level5/level5_fusion_environment.py:5
+    """Level5Environment with Level5FusionTask: the agent + five scripted wingmen, 5 -> 30 invaders in steps of five (36 drones)."""
+    TASK = "level5_fusion"
+
+    def __init__(self, GUI: bool = False, rl_frequency: int = 15, dome_radius: Optional[float] = None, **overrides):
+        super().__init__(dome_radius, rl_frequency, GUI, **overrides)
+
+
 class Level52BTEvaluationEnvironment(_SingleEnv):  # threatsense/level5/level5_eval_2bt_environment.py:12
     """Two behaviour-tree wingmen against the 30-slot invader table (Level52BTEvaluationTask).  As in the reference `reset` and `step`
     return an EMPTY observation (`{}`: level5_eval_2bt_environment.py:53-56,75), reward 0.0, and the info of
@@ -229,5 +237,5 @@ class Level52BTEvaluationEnvironment(_SingleEnv):  # threatsense/level5/level5_e
         return {}, 0.0, bool(done[0].item()), False, self._info()
 
 
-ENV_TASKS = {cls: cls.TASK for cls in (Level5DumbMultiObs, Level52BTEvaluationEnvironment, Level5C1FusionEnvironment, Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment, EvaluationEnvironment,
+ENV_TASKS = {cls: cls.TASK for cls in (Level5DumbMultiObs, Level52BTEvaluationEnvironment, Level5C1FusionEnvironment, Level5FusionEnvironment, Exp02vFinalEnvironment, Exp03vFinalEnvironment, Exp04vFinalEnvironment, Exp05vFinalEnvironment, EvaluationEnvironment,
                                        PyflytL2EnviromentModifiedV2, PyflytL3EnviromentV2, Level5Environment)}

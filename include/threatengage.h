@@ -56,6 +56,10 @@ enum {
   TE_TASK_LEVEL5_C1 = 11, /* threatsense/level5/level5_c1_fusion_environment.py + tasks/level5_c1_fusion_task.py: the RL agent and ONE scripted wingman
                           against 10 invader slots (4 in round 1, one more per round, 7 rounds; munition 49), the stacked observation of level5
                           (te_step_stacked) and the task's minimal reward (cfg.reward_model = TE_REWARD_L5_C1) */
+  TE_TASK_LEVEL5_FUSION = 12, /* threatsense/level5/level5_fusion_environment.py + tasks/level5_fusion_task.py: the RL agent + 5 scripted wingmen
+                          against 30 invader slots, FIVE more per round (5, 10, ... 30: 6 rounds; munition 105), Level5DumbMultiObjectTask's reward
+                          (the two compute_reward bodies are the same text) with the agent's death ending the episode; 36 drones per env: the
+                          stacked observation through te_step_stacked / te_observe_stacked (te_observe serves at most 32) */
   TE_TASK_EVALUATION = 8 /* level4/evaluation_environment.py + tasks/evaluation_task.py with behaviour-tree drivers only
                           (apps/threatengage_runner/stage03/experiments/01/evaluation_exp01_1bt_app_ready.py): cfg.evaluation = 1,
                           n_pursuers = number of drivers (default 1) */

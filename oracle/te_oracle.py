@@ -16,18 +16,25 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS: dict = {}
 
 
+def _sources():
+    """What the two oracle libraries are made of (oracle/Makefile): the restatement, the shared config table and the ABI header."""
+    root = os.path.dirname(_HERE)
+    return [os.path.join(_HERE, "te_oracle.c"), os.path.join(_HERE, "Makefile"), os.path.join(root, "dronechase_amd", "csrc", "te_config.c"),
+            os.path.join(root, "include", "threatengage.h")]
+
+
 def build(force: bool = False) -> None:
-    """Compile both precisions with gcc (oracle/Makefile)."""
-    out = os.path.join(_HERE, "_build", "libte_oracle_f64.so")
-    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(os.path.join(_HERE, "te_oracle.c")):
-        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    """Compile both precisions with gcc (oracle/Makefile) when a library is missing or older than one of its sources."""
+    outs = [os.path.join(_HERE, "_build", f"libte_oracle_{p}.so") for p in ("f64", "f32")]
+    newest = max(os.path.getmtime(f) for f in _sources() if os.path.exists(f))
+    if force or any(not os.path.exists(o) or os.path.getmtime(o) < newest for o in outs):
+        subprocess.run(["make", "-C", _HERE, "-s", "-B"], check=True)
 
 
 def lib(precision: str = "f64") -> C.CDLL:
     if precision not in _LIBS:
         path = os.path.join(_HERE, "_build", f"libte_oracle_{precision}.so")
-        if not os.path.exists(path):
-            build()
+        build()   # no-op when the libraries are newer than their sources
         L = C.CDLL(path)
         L.ote_create.restype = C.c_void_p
         L.ote_create.argtypes = [C.POINTER(K.Config)]

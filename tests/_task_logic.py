@@ -110,6 +110,12 @@ def config5_c1(default_config, g, **extra):
                           dome_radius=float(g["dome"]), **extra)
 
 
+def config5_fusion(default_config, g, **extra):
+    n = len(g["step"])
+    return default_config("level5_fusion", n_envs=n, substeps=0, observe_lag=0, motor_noise=0, auto_reset=0, seed=int(g["seed"]),
+                          dome_radius=float(g["dome"]), **extra)
+
+
 def config5_2bt(default_config, g, **extra):
     n = len(g["step"])
     return default_config("level5_2bt", n_envs=n, substeps=0, observe_lag=0, motor_noise=0, auto_reset=0, seed=int(g["seed"]),

@@ -43,6 +43,9 @@ KINDS = {
     # Level5C1FusionTask (level5_c1_fusion_task.py:82-111,448-485): the agent + one scripted wingman, 10 invader slots (4 + 1 per round, 7 rounds), the
     # minimal reward whose `last_distance` is set by the first call and never again
     "level5_c1": ("level5_c1_fusion_task", "Level5C1FusionTask", 2, 10, 7, 49, lambda r: min(r - 1 + 4, 10), False, "level5_c1_logic.npz"),
+    # Level5FusionTask (level5_fusion_task.py:81-112): the RL agent + 5 scripted wingmen, FIVE more invaders per round (6 rounds), the dumb task's reward,
+    # the agent's death ends the episode
+    "level5_fusion": ("level5_fusion_task", "Level5FusionTask", 6, 30, 6, 105, lambda r: min((r - 1) * 5 + 5, 30), False, "level5_fusion_logic.npz"),
     "level5_2bt": ("level5_2bt_evaluation_task", "Level52BTEvaluationTask", 2, 30, 26, 455, lambda r: min(r - 1 + 5, 30), True, "level5_2bt_logic.npz"),
 }
 KIND = "level5"

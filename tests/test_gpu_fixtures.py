@@ -7,6 +7,7 @@ not with the oracle: te_set_state -> te_step / te_observe -> outputs + te_get_st
   level5_dumb_logic.npz  the same cycle of Level5DumbMultiObjectTask: seven scripted wingmen, 30 invader slots, its own reward (te_step_students)
   level5_2bt_logic.npz   ... and of Level52BTEvaluationTask: two scripted wingmen, reward 0, fixed limit, kills per wingman (te_step + te_wingman_info)
   level5_c1_logic.npz    ... and of Level5C1FusionTask: agent + one scripted wingman, 4 -> 10 invaders, the minimal reward (te_step_stacked)
+  level5_fusion_logic.npz ... and of Level5FusionTask: the RL agent + five scripted wingmen, 36 drones per env (te_step_stacked)
   stage_logic.npz    stage02: L3Stage1.on_step_middle / on_step_end + level3 OffsetHandler / QuadcopterManager / Gun on 224 arenas;
                      stage01: PyflytL2EnviromentModifiedV2 reward / termination / replace_invader_if_close on 160 arenas
   lidar_math.npz     LidarMath binning of 1 000 body-frame vectors; add_features (closer wins) on 50 feature lists
@@ -138,6 +139,25 @@ def test_level5_c1_logic_fixture_through_the_c_abi(golden):
     env.reset()
     kept = _state(env, n, D)
     assert all(kept.ef(e, "LAST_DIST")[0] == before.ef(e, "LAST_DIST")[0] for e in range(n))
+    env.close()
+
+
+def test_level5_fusion_logic_fixture_through_the_c_abi(golden):
+    """Level5FusionTask (TE_TASK_LEVEL5_FUSION): RL agent + five scripted wingmen, 36 drones per env, five more invaders per round."""
+    from dronechase_amd import default_config
+    g = golden("level5_fusion_logic.npz")
+    cfg = T.config5_fusion(default_config, g)
+    env = _gpu(cfg)
+    n, D = cfg.n_envs, cfg.n_drones
+    _load(env, T.build_blob_drive(g, env.state_words()))
+    out = env.step_stacked(_zeros(n), terminal=False)
+    reward, done, info = (x.cpu().numpy() for x in out[-3:])
+    after = _state(env, n, D)
+    assert T.compare(g, reward, done, info, after) == n >= 200
+    c1, s1 = T.compare_commands(g, after, 1)
+    env.step_stacked(_zeros(n), terminal=False)
+    c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
+    assert c1 >= 900 and s1 >= 250 and c2 >= 700 and s2 >= 250, (c1, s1, c2, s2)
     env.close()
 
 

@@ -35,7 +35,7 @@ def _pair(N, task="level5", **over):
     return torch, cfg, BatchedEnv(cfg, "cuda:0"), O.OracleEnv(cfg, "f32")
 
 
-@pytest.mark.parametrize("task", ["level5", "level5_c1"])   # Level5_Task (6 wingmen, 12 slots) and Level5C1FusionTask (2 wingmen, 10 slots, its own reward)
+@pytest.mark.parametrize("task", ["level5", "level5_c1", "level5_fusion"])   # Level5_Task (6 wingmen, 12 slots), Level5C1FusionTask (2, 10, its own reward), Level5FusionTask (6, 30: 36 drones per env)
 def test_stacked_rollout_parity_with_resets_and_rounds(task):
     N, STEPS = 512, 60
     torch, cfg, g, o = _pair(N, task, motor_noise=0, max_step=25, seed=7)
@@ -72,7 +72,8 @@ def test_stacked_rollout_parity_with_resets_and_rounds(task):
         dirty_state[done & (gd_ == d)] = False
         dirty_cell_until[done & (gd_ == d)] = -1
     assert dones >= N            # every env auto-reset at least once (max_step 25)
-    assert flagged < 0.05 * N * STEPS and compared > 0.5 * N * STEPS and rewards_compared > 0.4 * N * STEPS, (flagged, compared, rewards_compared)
+    # cell-boundary ambiguities grow with the number of features in view: 18 drones per env in level5, 36 in level5_fusion
+    assert flagged < 0.05 * max(1.0, cfg.n_drones / 18) * N * STEPS and compared > 0.5 * N * STEPS and rewards_compared > 0.4 * N * STEPS, (flagged, compared, rewards_compared)
     dirty = dirty_state | (dirty_cell_until >= STEPS - 1)
     # the ring itself: stamps and feature counts exact, float words close, on envs that never met an ambiguity
     from dronechase_amd import config as K
@@ -163,14 +164,16 @@ def test_stacked_full_size_properties_and_api_errors():
         _lib.check(plain.L.te_observe_stacked(plain._h, None, None, None, None, None), "te_observe_stacked")
 
 
-def test_level5_vecenv_and_single_env_surface():
+@pytest.mark.parametrize("cls_name", ["Level5Environment", "Level5FusionEnvironment", "Level5C1FusionEnvironment"])
+def test_level5_vecenv_and_single_env_surface(cls_name):
     """The reference's level5 student observation dict (level5_envrionment.py:312-351,359-362) through the SB3 VecEnv
-    mirror and the single-env class."""
+    mirror and the single-env class; the fusion environments share it (level5_fusion_environment.py, level5_c1_fusion_environment.py:23-60)."""
     _gpu()
-    from dronechase_amd.envs import Level5Environment
+    from dronechase_amd import envs
     from dronechase_amd.pipeline import ReinforcementLearningPipeline
+    Level5Environment = getattr(envs, cls_name)
     n = 96
-    v = ReinforcementLearningPipeline.create_vectorized_environment(Level5Environment, {"dome_radius": 20, "rl_frequency": 15},
+    v = ReinforcementLearningPipeline.create_vectorized_environment(Level5Environment, {"rl_frequency": 15},
                                                                     n_envs=n, monitor=False, max_step=5)
     assert v.observation_space["stacked_spheres"].shape == (6, 3, 13, 26) and v.observation_space["validity_mask"].shape == (6,)
     obs = v.reset()
@@ -190,9 +193,10 @@ def test_level5_vecenv_and_single_env_surface():
         assert (obs["validity_mask"][live].sum(1) >= 1).all()
     assert saw_terminal
     v.close()
-    e = Level5Environment(dome_radius=20, rl_frequency=15)
+    e = Level5Environment(rl_frequency=15)
     o, info = e.reset()
     assert o["stacked_spheres"].shape == (6, 3, 13, 26) and not o["validity_mask"].any()
     o, r, term, trunc, info = e.step(np.array([0, 0, 1, 0.5], np.float32))
-    assert o["validity_mask"].sum() >= 1 and set(info) >= {"agent_kills", "allies_kills", "deads", "current_wave"} and trunc is False
+    assert o["validity_mask"].sum() >= 1 and trunc is False
+    assert info == {} if cls_name == "Level5C1FusionEnvironment" else set(info) >= {"agent_kills", "allies_kills", "deads", "current_wave"}
     e.close()

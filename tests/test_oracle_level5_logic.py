@@ -165,3 +165,31 @@ def test_c1_last_distance_outlives_a_reset(gc):
         orc.step_stacked(np.zeros((4, 4), np.float32), terminal=False)
     orc.reset()
     assert [float(Blob(orc.get_state(), 4, cfg.n_drones).ef(e, "LAST_DIST")[0]) for e in range(4)] == first
+
+
+# ---------------------------------------------------------------------------------------------------------------- Level5FusionTask
+@pytest.fixture(scope="module")
+def gf(golden):
+    return golden("level5_fusion_logic.npz")
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_oracle_reproduces_the_reference_fusion_step_cycle(gf, prec):
+    """Level5FusionTask: the RL agent + five scripted wingmen, 30 invader slots (36 drones per env), five more invaders per round."""
+    from oracle import te_oracle as O
+    g = gf
+    c = g["counts"]
+    assert (c[:, 0] > 0).sum() >= 20 and (c[:, 1] > 1).sum() >= 15 and (g["round"] >= 5).sum() >= 40 and (g["round_after"] != g["round"]).sum() >= 3
+    cfg = T.config5_fusion(O.default_config, g)
+    assert (cfg.n_pursuers, cfg.n_invaders, cfg.n_rounds, cfg.munition, cfg.invaders_per_round, cfg.agent_scripted, cfg.agent_death_terminates) == (6, 30, 6, 105, 5, 0, 1)
+    orc = O.OracleEnv(cfg, prec)
+    orc.set_state(T.build_blob_drive(g, orc.state_words()).w)
+    n, D = cfg.n_envs, cfg.n_drones
+    zeros = np.zeros((n, 4), np.float32)
+    out = orc.step_stacked(zeros, terminal=False)
+    after = Blob(orc.get_state(), n, D)
+    assert T.compare(g, out[-3], out[-2], out[-1], after) == n
+    c1, s1 = T.compare_commands(g, after, 1)
+    orc.step_stacked(zeros, terminal=False)
+    c2, s2 = T.compare_commands(g, Blob(orc.get_state(), n, D), 2)
+    assert c1 >= 900 and s1 >= 250 and c2 >= 700 and s2 >= 250, (c1, s1, c2, s2)
