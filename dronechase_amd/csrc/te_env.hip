@@ -825,9 +825,9 @@ struct te_env {
   std::vector<int32_t> done_idx;   // host I/O: the done envs of the step, and the host landing zone of their terminal rows
   std::vector<char> done_rows;
   int fill_mode = 1;       // TE_FILL_MODE: 0 pointer loop, 1 scalar buffer loop, 2 + s_setprio 3
-  int n_fill_waves = 256;  // fill waves of the sub-step kernel: one per CU of an MI355X; four per CU for the six-sphere background of
-                           // level5, where ~9 flight waves per SIMD would leave one fill wave too small a share of the issue slots
-                           // (605 -> 567 us/step; 512 / 1024 fill waves cost stage03 7 / 40 %); TE_FILL_WAVES overrides
+  int n_fill_waves = 256;  // fill waves of the sub-step kernel: one per CU of an MI355X; two per CU for the six-sphere background of
+                           // level5 (1.6 GB next to ~8 flight waves per SIMD: 128 / 256 / 512 / 1 024 / 2 048 waves -> 599 / 596 / 592 / 619 / 637 us
+                           // per step with the scalar loop; stage03 loses 12 / 35 % with 512 / 1 024); TE_FILL_WAVES overrides
   // profiling (te_profile_begin / te_profile_end)
   std::vector<hipEvent_t> events;
   int prof_cap = 0, prof_used = 0;
@@ -955,7 +955,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     return bail("te_create: cfg.drone_contact is built into engage_kernel: the level4 task family with P <= 6 and P + I <= 18");
   e->p.dense_min = kDenseMin;
   if (const char* v = getenv("TE_DENSE_MIN")) { int n = atoi(v); if (n >= 1 && n <= 65) e->p.dense_min = n; }
-  if (cfg->stacked_obs) e->n_fill_waves = 1024;
+  if (cfg->stacked_obs) e->n_fill_waves = 512;
   if (const char* v = getenv("TE_FILL_MODE")) e->fill_mode = atoi(v);
   if (const char* v = getenv("TE_FILL_WAVES")) { int n = atoi(v); if (n >= 1 && n <= (1 << 20)) e->n_fill_waves = n; }
   {
