@@ -133,6 +133,11 @@ struct StackParams {
   int n_obs;             // observers per env in the output buffers: 1 ([N,6,...]) or P ([N,P,6,...], te_step_students)
 };
 
+#ifdef TE_DEBUG_STAMPS   // phase stamps of every workgroup (tools/stacked_stamps.py), in the records the engage kernel's stamps used before this launch
+#define TE_SSTAMP(idx) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (g_te_dbg && threadIdx.x == 0) g_te_dbg[64 + blockIdx.x * 16 + (idx)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TE_SSTAMP(idx) do {} while (0)
+#endif
 constexpr int kStackThreads = 512;  // 8 waves: the block's LDS (73 KB at D = 18) allows two blocks per CU, i.e. 4 waves per SIMD (+ 9 % env-steps/s over 256 threads)
 __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, StackOut o) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
   const int env0 = blockIdx.x * kEPB, nvalid = min(kEPB, p.N - env0);
   const int tid = threadIdx.x, lane = tid & (kEPB - 1);
   const int ob = p.observer;
+  TE_SSTAMP(0);
   auto orow = [&](int l) { return (size_t)(env0 + l) * (size_t)p.n_obs + (size_t)ob; };   // row of (env, observer) in the output buffers
   auto row = [&](int rr, int l) -> uint32_t& { return sm[rr * kEPB + l]; };
   auto rowf = [&](int rr, int l) { return __uint_as_float(sm[rr * kEPB + l]); };
@@ -163,6 +169,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
   }
   if (tid < kEPB) { row(r.own_n(), tid) = 0u; }
   __syncthreads();
+  TE_SSTAMP(1);
   auto pos_of = [&](int s, int l) { return V3{rowf(r.pos() + 0 * D + s, l), rowf(r.pos() + 1 * D + s, l), rowf(r.pos() + 2 * D + s, l)}; };
   auto quat_of = [&](int pp, int l) { return Q4{rowf(r.quat() + 0 * P + pp, l), rowf(r.quat() + 1 * P + pp, l), rowf(r.quat() + 2 * P + pp, l), rowf(r.quat() + 3 * P + pp, l)}; };
 
@@ -232,6 +239,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
       __syncthreads();
     }
   }
+  TE_SSTAMP(2);
   // ---- (2) the agent's own snapshot and its draws
   if (tid < kEPB) {
     const int l = tid;
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
   }
   __threadfence_block();
   __syncthreads();
+  TE_SSTAMP(3);
   // ---- (3) neighbour k of env l: transform_features + add_features(invert) (lidar_math.py:186-345), sequentially
   {
     const int l = lane, k = tid >> 6;
@@ -309,6 +318,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
     if (k < 4) row(r.nb_n() + k, l) = count;
   }
   __syncthreads();
+  TE_SSTAMP(4);
   // ---- (4a) stack order -> output positions and the validity mask (fused_lidar.py:293-326,246-262)
   if (tid < kEPB && tid < nvalid) {
     const int l = tid;
@@ -340,6 +350,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  TE_SSTAMP(5);
   // ---- (4c) patches
   auto dst_of = [&](int l, int sphere_slot) -> float* {
     const uint32_t at = row(r.opos() + sphere_slot, l);
@@ -374,6 +385,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
       }
     }
   }
+  TE_SSTAMP(6);
   // ---- (4d) buffer reset of auto-reset envs (base_lidar.py:62-66: step 0 resets every LIDAR buffer)
   if (p.push)
     for (int it = tid; it < kEPB * P * TE_RING_DEPTH; it += blockDim.x) {
@@ -381,6 +393,7 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
       if (l >= nvalid || !row(r.done(), l)) continue;
       p.ring[(((size_t)(env0 + l) * P) * TE_RING_DEPTH + (size_t)e) * (size_t)p.entry_words] = 0u;
     }
+  TE_SSTAMP(7);
 }
 
 }  // namespace te
