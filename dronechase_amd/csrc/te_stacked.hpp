@@ -97,30 +97,47 @@ TE_DEV void draw_stack(const te_config& c, int env, int observer, uint32_t episo
     const U4 r = env_rng(c, env, RNG_STACK, (uint32_t)observer, (uint32_t)k, episode, step);   // every observer draws its own neighbourhood
     w[4 * k] = r.x; w[4 * k + 1] = r.y; w[4 * k + 2] = r.z; w[4 * k + 3] = r.w;
   }
-  uint32_t cand = armed_pursuers;  // candidates as a bit set; "position i of the array" = i-th set bit still unused
+  const uint32_t cand = armed_pursuers;  // candidates as a bit set; "position i of the array" = i-th set bit still unused
   const int nc = __popc(cand);
   const int want = 1 + (int)(((uint64_t)w[0] * 4u) >> 32);
   n = want < nc ? want : nc;
-  // partial Fisher-Yates over the candidates in slot order, on an explicit small array (nc <= 32)
-  uint8_t arr[kMaxD64];
-  int m = 0;
-  for (int p = 0; p < P; ++p) if ((cand >> p) & 1u) arr[m++] = (uint8_t)p;
+  // Partial Fisher-Yates over the candidates in slot order.  The array lives in registers: position x holds the x-th set bit of `cand`
+  // unless one of the (at most four) swaps moved something there — a dynamically indexed local array is scratch memory, and this
+  // phase runs on one wave of the block while the other seven wait (14 -> 3 us of every block).
+  uint32_t ov_pos = 0xFFFFFFFFu, ov_val = 0u;           // up to 4 overrides of positions >= the draw index: (position, value) bytes
+  auto nth = [&](int x) {                                // slot of the x-th set bit of cand
+    uint32_t m = cand;
+    for (int k = 0; k < x; ++k) m &= m - 1u;
+    return (uint32_t)(__ffs((int)m) - 1);
+  };
+  auto get = [&](int x) {
+    uint32_t v = nth(x);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if ((int)((ov_pos >> (8 * k)) & 0xFFu) == x) v = (ov_val >> (8 * k)) & 0xFFu;   // later overrides win: scanned in order
+    return v;
+  };
   who = 0u; age = 0u;
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (i >= n) break;
-    const int j = i + (int)(((uint64_t)w[1 + i] * (uint32_t)(nc - i)) >> 32);
-    const uint8_t t = arr[i]; arr[i] = arr[j]; arr[j] = t;
-    who |= (uint32_t)arr[i] << (8 * i);
-    age |= (uint32_t)(1 + (int)(((uint64_t)w[5 + i] * (uint32_t)(TE_RING_DEPTH - 1)) >> 32)) << (8 * i);
+    if (i < n) {
+      const int j = i + (int)(((uint64_t)w[1 + i] * (uint32_t)(nc - i)) >> 32);
+      const uint32_t ai = get(i), aj = get(j);
+      // arr[i] <-> arr[j]: position i is never read again (the next draws start at i + 1); position j now holds the old arr[i]
+      ov_pos = (ov_pos & ~(0xFFu << (8 * i))) | ((uint32_t)j << (8 * i));
+      ov_val = (ov_val & ~(0xFFu << (8 * i))) | (ai << (8 * i));
+      who |= aj << (8 * i);
+      age |= (uint32_t)(1 + (int)(((uint64_t)w[5 + i] * (uint32_t)(TE_RING_DEPTH - 1)) >> 32)) << (8 * i);
+    }
   }
-  uint8_t pm[TE_STACK_SPHERES];
-  for (int i = 0; i < TE_STACK_SPHERES; ++i) pm[i] = (uint8_t)i;
+  // uniform permutation of the six (sphere, valid) pairs: Fisher-Yates on 4-bit fields of one register
+  perm = 0x543210u;
+#pragma unroll
   for (int i = TE_STACK_SPHERES - 1; i >= 1; --i) {
     const int j = (int)(((uint64_t)w[9 + (TE_STACK_SPHERES - 1 - i)] * (uint32_t)(i + 1)) >> 32);
-    const uint8_t t = pm[i]; pm[i] = pm[j]; pm[j] = t;
+    const uint32_t vi = (perm >> (4 * i)) & 0xFu, vj = (perm >> (4 * j)) & 0xFu;
+    perm = (perm & ~(0xFu << (4 * i))) | (vj << (4 * i));
+    perm = (perm & ~(0xFu << (4 * j))) | (vi << (4 * j));
   }
-  perm = 0u;
-  for (int i = 0; i < TE_STACK_SPHERES; ++i) perm |= (uint32_t)pm[i] << (4 * i);
 }
 
 struct StackParams {
