@@ -69,12 +69,19 @@ TE_DEV Q4 inverse_of(Q4 q) {  // LidarMath._invert_quaternion (lidar_math.py:40-
   const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
   return Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2};
 }
-// cartesian -> (r_hat, theta, phi, cell)  (lidar_math.py:24-34,93-96,128-137)
+// cartesian -> (r_hat, theta, phi, cell)  (lidar_math.py:24-34,93-96,128-137), on the native rsq / rcp and the polynomial asin / atan2 of the
+// sub-step loop (1e-7 abs; te_engage.hpp: lidar_cell_fast): libm's acosf + atan2f were most of the instructions of phases (1) and (3)
 TE_DEV void spherical_of(const te_config& c, V3 v, float& rhat, float& theta, float& phi, int& cell) {
-  const float r = norm(v);
+  const float r2 = v.x * v.x + v.y * v.y + v.z * v.z;
+  float r = 0.0f;
   theta = 0.0f; phi = 0.0f;
-  if (r != 0.0f) { theta = acosf(clampf(v.z / r, -1.0f, 1.0f)); phi = atan2f(v.y, v.x); }
-  rhat = clampf(r / c.lidar_radius, 0.0f, 1.0f);
+  if (r2 != 0.0f) {
+    const float inv = rsq(r2);
+    r = r2 * inv;
+    theta = 0.5f * kPi - fast_asin(clampf(v.z * inv, -1.0f, 1.0f));
+    phi = fast_atan2(v.y, v.x);
+  }
+  rhat = clampf(r * rcp(c.lidar_radius), 0.0f, 1.0f);
   const int ti = min(max((int)(theta / kPi * (float)TE_LIDAR_NTHETA), 0), TE_LIDAR_NTHETA - 1);
   const int pi = min(max((int)((phi + kPi) / (2.0f * kPi) * (float)TE_LIDAR_NPHI), 0), TE_LIDAR_NPHI - 1);
   cell = ti * TE_LIDAR_NPHI + pi;
@@ -84,6 +91,8 @@ TE_DEV uint32_t* ring_entry_ptr(uint32_t* ring, int entry_words, int P, size_t e
 }
 // the ring is written and read by different waves of one block: read around the (write-through, not coherent) L1
 TE_DEV uint32_t load_fresh(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+typedef uint32_t te_w4 __attribute__((ext_vector_type(4)));
+TE_DEV te_w4 load_fresh4(const uint32_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const te_w4*>(p)); }   // entries and features are 16-byte aligned
 
 // (2) FusedLIDAR.bootstrap / randomize_stack draws (fused_lidar.py:73-81,246-262; lidar_buffer.py:110-157): n ~ U{1..4};
 // n distinct armed wingmen (the agent included) without replacement; an age ~ U{1..9} each; a uniform permutation of
@@ -303,21 +312,22 @@ __global__ __launch_bounds__(kStackThreads) void stacked_kernel(StackParams p, S
       const uint32_t* nb = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), q, s > 0 ? s : 0);
       if (s >= 1 && (int)load_fresh(nb) == s) {  // get_snapshot -> None otherwise (lidar_buffer.py:152-154)
         const uint32_t* own = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)(env0 + l), ob, step);
-        const V3 pn{__uint_as_float(load_fresh(nb + 2)), __uint_as_float(load_fresh(nb + 3)), __uint_as_float(load_fresh(nb + 4))};
-        const Q4 qn{__uint_as_float(load_fresh(nb + 5)), __uint_as_float(load_fresh(nb + 6)), __uint_as_float(load_fresh(nb + 7)), __uint_as_float(load_fresh(nb + 8))};
-        const V3 po{__uint_as_float(load_fresh(own + 2)), __uint_as_float(load_fresh(own + 3)), __uint_as_float(load_fresh(own + 4))};
-        const Q4 qo{__uint_as_float(load_fresh(own + 5)), __uint_as_float(load_fresh(own + 6)), __uint_as_float(load_fresh(own + 7)), __uint_as_float(load_fresh(own + 8))};
+        // one 16-byte load per feature and three per header instead of a dword load per word (each a round trip past the L1)
+        const te_w4 n0 = load_fresh4(nb), n1 = load_fresh4(nb + 4), n2 = load_fresh4(nb + 8), o0 = load_fresh4(own), o1 = load_fresh4(own + 4), o2 = load_fresh4(own + 8);
+        const V3 pn{__uint_as_float(n0.z), __uint_as_float(n0.w), __uint_as_float(n1.x)};
+        const Q4 qn{__uint_as_float(n1.y), __uint_as_float(n1.z), __uint_as_float(n1.w), __uint_as_float(n2.x)};
+        const V3 po{__uint_as_float(o0.z), __uint_as_float(o0.w), __uint_as_float(o1.x)};
+        const Q4 qo{__uint_as_float(o1.y), __uint_as_float(o1.z), __uint_as_float(o1.w), __uint_as_float(o2.x)};
         const M3 Rn = rotation(qn), Ro = rotation(inverse_of(qo));
-        const int cnt = (int)load_fresh(nb + 1);
+        const int cnt = (int)n0.y;
         const int base = r.nb_k() + k * 2 * r.F();
         count = 0u;
         for (int f = 0; f < cnt; ++f) {
-          const uint32_t* ff = nb + TE_RING_HEADER_WORDS + 4 * f;
-          const uint32_t meta = load_fresh(ff + 3);
+          const te_w4 ft = load_fresh4(nb + TE_RING_HEADER_WORDS + 4 * f);
+          const uint32_t meta = ft.w;
           if ((int)((meta >> 8) & 0xFFu) == ob) continue;  // synthetic echo of the observer itself (lidar_math.py:228-232)
-          const float R = __uint_as_float(load_fresh(ff)) * c.lidar_radius, th = __uint_as_float(load_fresh(ff + 1)), ph = __uint_as_float(load_fresh(ff + 2));
-          float st, ct, sp, cp;
-          sincosf(th, &st, &ct); sincosf(ph, &sp, &cp);
+          const float R = __uint_as_float(ft.x) * c.lidar_radius, th = __uint_as_float(ft.y), ph = __uint_as_float(ft.z);
+          const float st = sin_rev(th * (0.5f / kPi)), ct = cos_rev(th * (0.5f / kPi)), sp = sin_rev(ph * (0.5f / kPi)), cp = cos_rev(ph * (0.5f / kPi));   // v_sin / v_cos take revolutions
           const V3 cart{R * st * cp, R * st * sp, R * ct};                          // spherical_to_cartesian (lidar_math.py:16-22)
           const V3 glob = mul(Rn, cart);
           const V3 loc = mul(Ro, V3{glob.x + pn.x - po.x, glob.y + pn.y - po.y, glob.z + pn.z - po.z});
