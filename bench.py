@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -198,15 +200,30 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def marker_overhead_ms() -> float:
+        """What a pair of event records adds to whatever sits between them on a busy queue: two records back to back behind a small
+        kernel, median of 64 (5.4 us on an MI355X: the time the command processor takes from one marker to the next).  Subtracted
+        from every bracket of kernel_times()."""
+        scratch = torch.empty((n_local, 4), dtype=torch.float32, device=device)
+        pairs = []
+        for _ in range(64):
+            env.random_actions(1, 0, out=scratch)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize(device)
+        return float(np.median([a.elapsed_time(b) for a, b in pairs]))
+
     def kernel_times(first: int, count: int):
-        """Average duration of the two kernels over `count` more steps, from HIP events on the stream te_step launches on
-        (te_profile_begin/end).  A SEPARATE short loop: each event record costs ~3 us of stream time, which the
-        headline loop must not pay."""
+        """Average duration of the two kernels over the `count` steps starting at rollout step `first`, from HIP events on the stream
+        te_step launches on (te_profile_begin/end), minus the markers' own cost.  A SEPARATE loop (regime() replays the window it
+        timed on the wall clock from a saved state): the headline loop must not pay for event records."""
         env.profile_begin(count)
         for i in range(count):
             one_step((first + i) % n_batches if pregen else first + i)
         torch.cuda.synchronize(device)
-        return env.profile_end()
+        k1, k2, n = env.profile_end()
+        return max(k1 - ev_over_ms, 0.0), max(k2 - ev_over_ms, 0.0), n, (k1, k2)
 
     D = cfg.n_drones
     per_drone = 2 * 176                                           # sub-step kernel: state read + written per armed drone
@@ -221,14 +238,19 @@ def main():
         return k1, k1 + alg_k2
 
     def regime(first: int, count: int, n_events: int, label: str) -> dict:
-        """One measured regime of the rollout: `count` steps on the wall clock (no events), then `n_events` more steps with the
-        kernels bracketed by HIP events.  Every fraction of the HBM peak is computed from the WALL time of the step."""
+        """One measured regime of the rollout: `count` steps on the wall clock (no events), then — unless n_events is 0 — the same
+        `count` steps once more from the saved state with the kernels bracketed by HIP events.  Every fraction of the HBM peak is
+        computed from the WALL time of the step."""
         a0 = armed_per_env() if rank == 0 else 0.0
+        replay = use_events and n_events > 0
+        saved = env.get_state().clone() if replay else None
         el = timed(first, count)
         a1 = armed_per_env() if rank == 0 else 0.0
-        k1_ms = k2_ms = 0.0; n_prof = 0
-        if use_events and n_events > 0:
-            k1_ms, k2_ms, n_prof = kernel_times(first + count, n_events)
+        k1_ms = k2_ms = 0.0; n_prof = 0; raw = (0.0, 0.0)
+        if replay:   # the SAME steps again from the saved state (the rollout is deterministic), this time with the kernels bracketed by events
+            env.set_state(saved)
+            k1_ms, k2_ms, n_prof, raw = kernel_times(first, count)
+            del saved
         armed = 0.5 * (a0 + a1)
         ms = 1e3 * el / count
         b_k1, b_step = priced(armed)
@@ -239,24 +261,26 @@ def main():
                                      "frac": b_step * n_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "from": "wall-clock ms_per_step"}}
         if n_prof:
             out["kernels"] = {"substeps_kernel_ms": k1_ms, "engage_observe_kernel_ms": k2_ms, "launches_timed": n_prof,
-                              "timed_in": "a separate loop of the next steps, HIP events on te_step's stream",
+                              "timed_in": "a replay of the same steps from the state saved at the start of the window, HIP events on te_step's stream",
+                              "event_brackets_raw_ms": list(raw), "event_pair_overhead_ms": ev_over_ms,
                               "substeps_kernel_hbm_frac": b_k1 * n_local / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "engage_observe_kernel_hbm_frac": alg_k2 * n_local / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         return out, el, (k1_ms, k2_ms, n_prof, armed)
 
     use_events = not args.no_profile_events
     env.reset()
+    ev_over_ms = marker_overhead_ms() if use_events else 0.0
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize(device)
     # ---- headline: EXACTLY args.steps steps after args.warmup, nothing else in the timed region
-    head, elapsed, (k1_ms, k2_ms, n_prof, armed) = regime(args.warmup, args.steps, min(args.steps, 32), "headline")
+    head, elapsed, (k1_ms, k2_ms, n_prof, armed) = regime(args.warmup, args.steps, args.steps, "headline")
     done_frac = float(env.done.float().mean().item())
     extra = {}
     if not args.headline_only:
         # ---- steady state: the rollout gets heavier as episodes progress (more invaders per wave, spread over more slots);
         # fast-forward to step args.steady_after (untimed), then time args.steady_steps steps the same way
-        pos = args.warmup + args.steps + (min(args.steps, 32) if use_events else 0)
+        pos = args.warmup + args.steps   # (the event replay of a window ends where the window ended)
         for i in range(pos, max(pos, args.steady_after)):
             one_step(i % n_batches if pregen else i)
         pos = max(pos, args.steady_after)
@@ -315,7 +339,10 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": dom_bytes * n_local, "avg_launch_ms": dom_ms,
-                               "launches_timed": n_prof, "timed_in": "a separate loop of the steps right after the headline window (HIP events on te_step's stream)",
+                               "launches_timed": n_prof,
+                               "timed_in": "a replay of the headline window from the state saved at its start: the same steps, HIP events on te_step's stream, "
+                                           "minus event_pair_overhead_ms per bracket (two event records back to back on a busy queue, measured in this run)",
+                               "event_pair_overhead_ms": ev_over_ms, "event_bracket_raw_ms": head["kernels"]["event_brackets_raw_ms"][0 if dom_name == "substeps_kernel" else 1],
                                "armed_drones_per_env": armed,
                                "valu_issue_frac_substeps_kernel": (armed * n_local / 64.0) * SUBSTEPS * VALU_CLOCKS_PER_DRONE_SUBSTEP
                                                                   / (SIMDS * CLOCK_HZ * k1_ms * 1e-3),
