@@ -10,3 +10,6 @@ row --task exp05 --envs-per-gpu 65536
 row --task evaluation --envs-per-gpu 65536
 for n in 8192 16384 32768 65536 131072; do row --task stage03 --envs-per-gpu $n; done
 row --task level5 --envs-per-gpu 65536
+row --task level5_c1 --envs-per-gpu 65536
+row --task level5_fusion --envs-per-gpu 65536
+row --task level5_2bt --envs-per-gpu 65536
