@@ -199,6 +199,36 @@ def test_ragged_env_counts():
         gpu.close(); orc.close()
 
 
+def test_ragged_env_counts_of_the_stacked_tasks():
+    """The same for te_step_stacked / te_observe_stacked: level5 (18 drones), level5_c1 (12) and level5_fusion (36: the 64-bit masks and
+    agent_rows_kernel) with 1, 63 and 65 envs."""
+    torch = _gpu()
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    from oracle import te_oracle as O
+
+    for task in ("level5", "level5_c1", "level5_fusion"):
+        for N in (1, 63, 65):
+            cfg = default_config(task, n_envs=N, motor_noise=0, seed=9)
+            orc = O.OracleEnv(cfg, "f32")
+            gpu = BatchedEnv(cfg, "cuda:0")
+            orc.reset(); gpu.reset()
+            gs, gm, gi, ga = (x.cpu().numpy() for x in gpu.observe_stacked())
+            os_, om, oi, oa = orc.observe_stacked()
+            np.testing.assert_array_equal(gm, om); np.testing.assert_allclose(gs, os_, atol=OBS_TOL); np.testing.assert_allclose(gi, oi, atol=OBS_TOL)
+            for s in range(4):
+                a = orc.random_actions(3, s)
+                os_, om, oi, oa, orew, odone, oinfo = orc.step_stacked(a)
+                ok = orc.stack_margins() > 5e-5       # cell decisions inside the float tolerance are not comparable
+                gs, gm, gi, ga, grew, gdone, ginfo = (x.cpu().numpy() for x in gpu.step_stacked(torch.from_numpy(a).cuda()))
+                np.testing.assert_array_equal(gdone, odone); np.testing.assert_array_equal(ginfo, oinfo)
+                np.testing.assert_array_equal(gm[ok], om[ok])
+                np.testing.assert_allclose(gs[ok], os_[ok], atol=OBS_TOL)
+                np.testing.assert_allclose(gi, oi, atol=OBS_TOL)
+                np.testing.assert_allclose(grew, orew, atol=2e-3)
+            gpu.close(); orc.close()
+
+
 def test_random_actions_match_oracle():
     torch = _gpu()
     from dronechase_amd import default_config
