@@ -31,6 +31,7 @@
 
 #include "te_logic.hpp"
 #include "te_stacked.hpp"
+#include "te_stackview.hpp"
 #include "te_engage.hpp"
 
 namespace te {
@@ -808,6 +809,8 @@ struct te_env {
   int family;
   size_t lds_bytes;
   size_t stack_lds_bytes = 0;  // stacked_kernel (level5)
+  int stack_regs = 0;          // 18 / 37: ring_push_kernel<DM> + stack_view_kernel<DM> (te_stackview.hpp); 0: stacked_kernel (more than 37 drones, TE_STACKED=lds)
+  size_t view_lds_bytes = 0;
   size_t dbg_words = 0;       // diagnostic builds: length of p.dbg
   int engage_regs = 0;         // 1 = engage_kernel<2, 9>, 2 = engage_kernel<6, 12> (level4 family), 3 = engage_stage02_kernel<2, 8>, 4 = engage_stage01_kernel (te_engage.hpp: the env in registers, one wave per
                                // chunk); 0 = engage_observe_kernel (LDS phases): other shapes, stage01 / stage02, TE_ENGAGE=lds
@@ -1017,6 +1020,11 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     const size_t snap_bytes = (size_t)snap_words(D, cfg->n_pursuers) * e->p.Npad * 4;
     const size_t ring_bytes = (size_t)cfg->n_envs * cfg->n_pursuers * TE_RING_DEPTH * e->p.entry_words * 4;
     hipError_t le = hipFuncSetAttribute(reinterpret_cast<const void*>(&stacked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->stack_lds_bytes);
+    e->stack_regs = D <= 18 ? 18 : (D <= 37 ? 37 : 0);
+    if (const char* v = getenv("TE_STACKED")) { if (!strcmp(v, "lds")) e->stack_regs = 0; }
+    e->view_lds_bytes = (size_t)view_lds_rows(D) * kEPB * sizeof(uint32_t);
+    if (le == hipSuccess && e->stack_regs == 18) le = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_view_kernel<18>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->view_lds_bytes);
+    if (le == hipSuccess && e->stack_regs == 37) le = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_view_kernel<37>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->view_lds_bytes);
     if (le != hipSuccess || hipMalloc(&e->p.snap, snap_bytes) != hipSuccess || hipMalloc(&e->p.ring, ring_bytes) != hipSuccess)
       return bail("te_create: stacked observation buffers (ring / snapshot / LDS) could not be set up");
     TE_HIP_OR_BAIL(hipMemsetAsync(e->p.snap, 0, snap_bytes, nullptr));
@@ -1241,6 +1249,17 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   });
   if (stack) {
     // the first launch pushes this step's ring entries (all wingmen) and serves observer 0; te_step_students adds one launch per further wingman
+    if (e->stack_regs) {  // one wave per (chunk, wingman) pushes this step's ring entries, then one 5-wave workgroup per chunk and observer
+      StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 1, 0, n_obs};
+      const unsigned push_waves = (unsigned)b2 * (unsigned)p.cfg.n_pursuers;
+      if (e->stack_regs == 18) hipLaunchKernelGGL((ring_push_kernel<18>), dim3(push_waves), dim3(64), 0, st, sp);
+      else hipLaunchKernelGGL((ring_push_kernel<37>), dim3(push_waves), dim3(64), 0, st, sp);
+      for (int ob = 0; ob < n_obs; ++ob) {
+        sp.push = ob == 0 ? 1 : 0; sp.observer = ob;   // the first view clears the ring of auto-reset envs when it is through
+        if (e->stack_regs == 18) hipLaunchKernelGGL((stack_view_kernel<18>), dim3(b2), dim3(kViewThreads), e->view_lds_bytes, st, sp, *stack);
+        else hipLaunchKernelGGL((stack_view_kernel<37>), dim3(b2), dim3(kViewThreads), e->view_lds_bytes, st, sp, *stack);
+      }
+    } else
     for (int ob = 0; ob < n_obs; ++ob) {
       StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, ob == 0 ? 1 : 0, ob, n_obs};
       hipLaunchKernelGGL(stacked_kernel, dim3(b2), dim3(kStackThreads), e->stack_lds_bytes, st, sp, *stack);
@@ -1393,7 +1412,9 @@ __attribute__((visibility("default"))) int te_observe_stacked(te_env* e, float* 
     hipLaunchKernelGGL(observe_kernel, dim3(blocks), dim3(256), e->lds_bytes, st, p, ObsOut{nullptr, obs_inertial, obs_last_action});
   }
   StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 0, 0, 1};
-  hipLaunchKernelGGL(stacked_kernel, dim3(blocks), dim3(kStackThreads), e->stack_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
+  if (e->stack_regs == 18) hipLaunchKernelGGL((stack_view_kernel<18>), dim3(blocks), dim3(kViewThreads), e->view_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
+  else if (e->stack_regs == 37) hipLaunchKernelGGL((stack_view_kernel<37>), dim3(blocks), dim3(kViewThreads), e->view_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
+  else hipLaunchKernelGGL(stacked_kernel, dim3(blocks), dim3(kStackThreads), e->stack_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
   TE_HIP(hipGetLastError());
   return 0;
 }

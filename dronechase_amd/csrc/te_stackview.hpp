@@ -1,0 +1,240 @@
+// te_stackview.hpp — level5's stacked observation in two launches of single-purpose waves (round 2), replacing the phase chain of
+// stacked_kernel (te_stacked.hpp: one 512-thread workgroup per 64 envs, ~20 barriers, every operand through LDS, 2 workgroups per CU):
+//
+//   ring_push_kernel<DM>   one wave per (64-env chunk, wingman), lane = env.  The wingman's own sphere — every other armed drone re-framed,
+//                          binned, closer wins per cell — lives in registers (compile-time slot capacity DM, run-time predicates) and goes
+//                          straight into this step's ring entry.  No LDS, no barrier.                      (stacked_kernel phase 1)
+//   stack_view_kernel<DM>  one 5-wave workgroup per chunk for one observer: wave 0 draws the neighbourhood and lists the observer's own
+//                          entry, waves 1-4 re-project one drawn snapshot each (farther wins) into a list of their own in LDS; then stack
+//                          order + validity mask, ones into the terminal tiles of auto-reset envs, the patches, and the ring reset of
+//                          auto-reset envs.  4 barriers.                                                   (phases 2, 3, 4)
+//
+// Same arithmetic, same helpers (spherical_of, rotate_by, draw_stack, ring layout) and the same order of every farther- / closer-wins
+// decision as stacked_kernel, which stays as the fallback for shapes beyond DM = 37 and behind TE_STACKED=lds.
+#pragma once
+#include "te_stacked.hpp"
+
+namespace te {
+
+template <int DM>
+__global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
+  const te_config& c = p.cfg;
+  const int D = p.D, P = c.n_pursuers;
+  const SnapRows sr{D, P};
+  const int chunk = blockIdx.x / P, pp = blockIdx.x - chunk * P;
+  const int lane = threadIdx.x, env = chunk * kEPB + lane;
+  if (env >= p.N) return;
+  auto snap = [&](int w) { return p.snap[(size_t)w * p.Npad + env]; };
+  const uint64_t A = (uint64_t)snap(sr.armed()) | ((uint64_t)snap(sr.armed_hi()) << 32);
+  if (!((A >> pp) & 1u)) return;   // a disarmed wingman publishes nothing: its ring keeps the older entries
+  const int step = (int)snap(sr.step());
+  const V3 me{__uint_as_float(snap(sr.pos() + 0 * D + pp)), __uint_as_float(snap(sr.pos() + 1 * D + pp)), __uint_as_float(snap(sr.pos() + 2 * D + pp))};
+  const Q4 q = quat_of_euler(V3{__uint_as_float(snap(sr.euler() + 0 * P + pp)), __uint_as_float(snap(sr.euler() + 1 * P + pp)), __uint_as_float(snap(sr.euler() + 2 * P + pp))});
+  const Q4 qi = inverse_of(q);
+  // ---- the sphere of wingman pp: (r_hat, theta, phi, cell) of every other armed drone
+  float rh[DM], th[DM], ph[DM]; uint32_t cell[DM];
+#pragma unroll
+  for (int j = 0; j < DM; ++j) {
+    cell[j] = 0xFFFFFFFFu; rh[j] = 1.0f; th[j] = 0.0f; ph[j] = 0.0f;
+    if (j < D && j != pp && ((A >> j) & 1u)) {
+      const V3 pj{__uint_as_float(snap(sr.pos() + 0 * D + j)), __uint_as_float(snap(sr.pos() + 1 * D + j)), __uint_as_float(snap(sr.pos() + 2 * D + j))};
+      const V3 local = rotate_by(qi, sub(pj, me));
+      int cl;
+      spherical_of(c, local, rh[j], th[j], ph[j], cl);
+      cell[j] = (uint32_t)cl;
+    }
+  }
+  // ---- closer wins per cell (lidar_math.py:262-311), as in stacked_kernel: j CLAIMS its cell if it is in view with r_hat < 1; the kept
+  // feature of a cell is its closest claimant (ties: lowest slot); cells appear in the entry in the order of their first claimant
+  uint32_t* ent = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)env, pp, step);
+  uint32_t n = 0u;
+#pragma unroll
+  for (int j = 0; j < DM; ++j) {
+    const bool claim = cell[j] != 0xFFFFFFFFu && rh[j] < 1.0f;
+    bool lead = claim;
+    float br = rh[j], bt = th[j], bp = ph[j]; int bw = j;
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+      if (k == j) continue;
+      const bool same = claim && cell[k] == cell[j] && rh[k] < 1.0f;   // cell[k] == 0xFFFFFFFF never equals a claimed cell
+      if (same && k < j) lead = false;
+      if (same && (rh[k] < br || (rh[k] == br && k < bw))) { br = rh[k]; bt = th[k]; bp = ph[k]; bw = k; }
+    }
+    if (lead) {
+      const uint32_t meta = (uint32_t)(bw < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) | ((uint32_t)bw << 8);
+      *reinterpret_cast<uint4*>(ent + TE_RING_HEADER_WORDS + 4 * n) = make_uint4(__float_as_uint(br), __float_as_uint(bt), __float_as_uint(bp), meta);
+      n += 1u;
+    }
+  }
+  *reinterpret_cast<uint4*>(ent) = make_uint4((uint32_t)step, n, __float_as_uint(me.x), __float_as_uint(me.y));
+  *reinterpret_cast<uint4*>(ent + 4) = make_uint4(__float_as_uint(me.z), __float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z));
+  *reinterpret_cast<uint4*>(ent + 8) = make_uint4(__float_as_uint(q.w), 0u, 0u, 0u);
+}
+
+// LDS of stack_view_kernel: five lists (own, four neighbours) of up to F = D - 1 (cell | type << 16, r_hat) pairs per env, then the rows below
+struct ViewRows {
+  int F;
+  TE_DEV int list(int k) const { return k * 2 * F; }        // k = 0 own, 1..4 neighbours
+  TE_DEV int n(int k) const { return 10 * F + k; }          // kept features of list k, or 0xFFFFFFFF = no sphere
+  TE_DEV int dn() const { return 10 * F + 5; }
+  TE_DEV int dwho() const { return dn() + 1; }
+  TE_DEV int dage() const { return dn() + 2; }
+  TE_DEV int dperm() const { return dn() + 3; }
+  TE_DEV int step() const { return dn() + 4; }
+  TE_DEV int done() const { return dn() + 5; }
+  TE_DEV int opos() const { return dn() + 6; }              // 5
+  TE_DEV int total() const { return opos() + 5; }
+};
+__host__ __device__ inline int view_lds_rows(int D) { return 10 * (D - 1) + 5 + 6 + 5; }
+constexpr int kViewThreads = 5 * 64;
+
+template <int DM>
+__global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p, StackOut o) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+  const te_config& c = p.cfg;
+  const int D = p.D, P = c.n_pursuers, ob = p.observer;
+  const SnapRows sr{D, P};
+  const ViewRows r{D - 1};
+  const int env0 = blockIdx.x * kEPB, nvalid = min(kEPB, p.N - env0);
+  const int tid = threadIdx.x, l = tid & (kEPB - 1), role = tid >> 6;   // role 0: draws + own list; 1..4: neighbour role - 1
+  const int env = env0 + l;
+  const bool valid = l < nvalid;
+  auto row = [&](int rr, int ll) -> uint32_t& { return sm[rr * kEPB + ll]; };
+  auto rowf = [&](int rr, int ll) { return __uint_as_float(sm[rr * kEPB + ll]); };
+  auto snap = [&](int w) { return p.snap[(size_t)w * p.Npad + env]; };
+  auto orow = [&](int ll) { return (size_t)(env0 + ll) * (size_t)p.n_obs + (size_t)ob; };
+  // ---- (2) the observer's own snapshot and its draws (wave 0), with the own sphere listed out of the ring
+  if (role == 0) {
+    uint32_t n = 0u, who = 0u, age = 0u, perm = 0u, own_n = 0xFFFFFFFFu;
+    const int step = valid ? (int)snap(sr.step()) : 0;
+    const uint32_t armed = valid ? snap(sr.armed()) : 0u;
+    bool own_ok = valid && step >= 1;
+    if (own_ok) {
+      const uint32_t* own = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)env, ob, step);
+      if (p.push) own_ok = ((armed >> ob) & 1u) != 0u;            // pushed by ring_push_kernel iff the observer is armed
+      else own_ok = (int)load_fresh(own) == step;                 // te_observe_stacked: whatever the ring holds
+      if (own_ok) {
+        const int cnt = (int)load_fresh(own + 1);
+        for (int k = 0; k < cnt; ++k) {
+          const te_w4 f = load_fresh4(own + TE_RING_HEADER_WORDS + 4 * k);
+          const float thv = __uint_as_float(f.y), phv = __uint_as_float(f.z);
+          const int ti = min(max((int)(thv / kPi * (float)TE_LIDAR_NTHETA), 0), TE_LIDAR_NTHETA - 1);
+          const int pi = min(max((int)((phv + kPi) / (2.0f * kPi) * (float)TE_LIDAR_NPHI), 0), TE_LIDAR_NPHI - 1);
+          row(r.list(0) + 2 * k, l) = (uint32_t)(ti * TE_LIDAR_NPHI + pi) | ((f.w & 0xFFu) << 16);
+          row(r.list(0) + 2 * k + 1, l) = f.x;
+        }
+        own_n = (uint32_t)cnt;
+      }
+    }
+    if (own_ok) {
+      int nn;
+      draw_stack(c, env, ob, valid ? snap(sr.episode()) : 0u, (uint32_t)step, armed & ((1u << P) - 1u), P, nn, who, age, perm);
+      n = (uint32_t)nn;
+    }
+    row(r.n(0), l) = own_n;   // 0xFFFFFFFF: _build_valid_spheres returns [] without an own snapshot (fused_lidar.py:91-96)
+    row(r.dn(), l) = n; row(r.dwho(), l) = who; row(r.dage(), l) = age; row(r.dperm(), l) = perm;
+    row(r.step(), l) = (uint32_t)step; row(r.done(), l) = valid ? snap(sr.done()) : 0u;
+  }
+  __syncthreads();
+  // ---- (3) neighbour k of env l: transform_features + add_features(invert) (lidar_math.py:186-345), sequentially, one wave per k
+  if (role >= 1) {
+    const int k = role - 1;
+    uint32_t count = 0xFFFFFFFFu;
+    if (valid && k < (int)row(r.dn(), l)) {
+      const int step = (int)row(r.step(), l);
+      const int q = (int)((row(r.dwho(), l) >> (8 * k)) & 0xFFu), a = (int)((row(r.dage(), l) >> (8 * k)) & 0xFFu);
+      const int s = step - (a - 1);
+      const uint32_t* nb = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)env, q, s > 0 ? s : 0);
+      if (s >= 1 && (int)load_fresh(nb) == s) {  // get_snapshot -> None otherwise (lidar_buffer.py:152-154)
+        const uint32_t* own = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)env, ob, step);
+        const te_w4 n0 = load_fresh4(nb), n1 = load_fresh4(nb + 4), n2 = load_fresh4(nb + 8), o0 = load_fresh4(own), o1 = load_fresh4(own + 4), o2 = load_fresh4(own + 8);
+        const V3 pn{__uint_as_float(n0.z), __uint_as_float(n0.w), __uint_as_float(n1.x)};
+        const Q4 qn{__uint_as_float(n1.y), __uint_as_float(n1.z), __uint_as_float(n1.w), __uint_as_float(n2.x)};
+        const V3 po{__uint_as_float(o0.z), __uint_as_float(o0.w), __uint_as_float(o1.x)};
+        const Q4 qo{__uint_as_float(o1.y), __uint_as_float(o1.z), __uint_as_float(o1.w), __uint_as_float(o2.x)};
+        const M3 Rn = rotation(qn), Ro = rotation(inverse_of(qo));
+        const int cnt = (int)n0.y;
+        const int base = r.list(1 + k);
+        count = 0u;
+        for (int f = 0; f < cnt; ++f) {
+          const te_w4 ft = load_fresh4(nb + TE_RING_HEADER_WORDS + 4 * f);
+          const uint32_t meta = ft.w;
+          if ((int)((meta >> 8) & 0xFFu) == ob) continue;  // synthetic echo of the observer itself (lidar_math.py:228-232)
+          const float R = __uint_as_float(ft.x) * c.lidar_radius, thv = __uint_as_float(ft.y), phv = __uint_as_float(ft.z);
+          const float st = sin_rev(thv * (0.5f / kPi)), ct = cos_rev(thv * (0.5f / kPi)), sp = sin_rev(phv * (0.5f / kPi)), cp = cos_rev(phv * (0.5f / kPi));
+          const V3 cart{R * st * cp, R * st * sp, R * ct};                          // spherical_to_cartesian (lidar_math.py:16-22)
+          const V3 glob = mul(Rn, cart);
+          const V3 loc = mul(Ro, V3{glob.x + pn.x - po.x, glob.y + pn.y - po.y, glob.z + pn.z - po.z});
+          float rhat, t2, p2; int cl;
+          spherical_of(c, loc, rhat, t2, p2, cl);
+          int at = -1;
+          for (uint32_t j = 0; j < count; ++j) if ((row(base + 2 * j, l) & 0xFFFFu) == (uint32_t)cl) at = (int)j;
+          bool put = true;
+          if (at >= 0) { const float cur = rowf(base + 2 * at + 1, l); put = cur < 1.0f ? rhat > cur : true; }
+          else at = (int)count++;
+          if (put) { row(base + 2 * at, l) = (uint32_t)cl | ((meta & 0xFFu) << 16); row(base + 2 * at + 1, l) = __float_as_uint(rhat); }
+        }
+      }
+    }
+    row(r.n(1 + k), l) = count;
+  }
+  __syncthreads();
+  // ---- (4a) stack order -> output positions and the validity mask (fused_lidar.py:293-326,246-262)
+  if (role == 0 && valid) {
+    const bool done = row(r.done(), l) != 0u;
+    uint8_t* M = (done ? o.t_mask : o.mask);
+    const bool any = row(r.n(0), l) != 0xFFFFFFFFu;
+    int sidx[5]; int nv = 0;   // stack index of own = 0, of valid neighbour k = 1 + (valid neighbours before k)
+    sidx[0] = any ? nv++ : -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sidx[1 + k] = (any && row(r.n(1 + k), l) != 0xFFFFFFFFu) ? nv++ : -1;
+    const uint32_t perm = row(r.dperm(), l);
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      uint32_t at = 0xFFu;
+      if (sidx[s] >= 0) for (int i = 0; i < TE_STACK_SPHERES; ++i) if ((int)((perm >> (4 * i)) & 0xFu) == sidx[s]) at = (uint32_t)i;
+      row(r.opos() + s, l) = at;
+    }
+    if (M) for (int i = 0; i < TE_STACK_SPHERES; ++i) M[orow(l) * TE_STACK_SPHERES + i] = (any && (int)((perm >> (4 * i)) & 0xFu) < nv) ? 1 : 0;
+    if (done && o.mask) for (int i = 0; i < TE_STACK_SPHERES; ++i) o.mask[orow(l) * TE_STACK_SPHERES + i] = 0;  // reset observation
+  }
+  // ---- (4b) terminal tiles of auto-reset envs are not pre-filled: ones first (rare, block-uniform test)
+  const bool lane_done = role == 0 && valid && row(r.done(), l) != 0u;
+  if (__syncthreads_or(lane_done ? 1 : 0)) {
+    if (o.t_stacked)
+      for (int ll = 0; ll < nvalid; ++ll) {
+        if (!row(r.done(), ll)) continue;
+        float* base = o.t_stacked + orow(ll) * TE_OBS_STACKED_WORDS;
+        for (int e = tid; e < TE_OBS_STACKED_WORDS; e += kViewThreads) base[e] = 1.0f;
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // ---- (4c) patches: every wave its own list (own sphere: time = 1/10, perception_snapshot.py:36-37; neighbour: normalized_delta of the snapshot)
+  if (valid) {
+    const uint32_t n = row(r.n(role), l);
+    const uint32_t at = row(r.opos() + role, l);
+    float* basep = row(r.done(), l) ? o.t_stacked : o.stacked;
+    if (n != 0xFFFFFFFFu && at != 0xFFu && basep) {
+      float* d0 = basep + orow(l) * TE_OBS_STACKED_WORDS + (size_t)at * TE_OBS_LIDAR_WORDS;
+      const float tnorm = role == 0 ? 0.1f : (float)((row(r.dage(), l) >> (8 * (role - 1))) & 0xFFu) / (float)TE_RING_DEPTH;
+      const int base = r.list(role);
+      for (uint32_t f = 0; f < n; ++f) {
+        const uint32_t w = row(base + 2 * f, l);
+        float* d = d0 + (w & 0xFFFFu);
+        d[0] = rowf(base + 2 * f + 1, l); d[TE_LIDAR_CELLS] = (float)(w >> 16) / 5.0f; d[2 * TE_LIDAR_CELLS] = tnorm;
+      }
+    }
+  }
+  // ---- (4d) buffer reset of auto-reset envs (base_lidar.py:62-66: step 0 resets every LIDAR buffer): after every wave has read the ring
+  if (p.push) {
+    __syncthreads();
+    for (int it = tid; it < kEPB * P * TE_RING_DEPTH; it += kViewThreads) {
+      const int ll = it & (kEPB - 1), e = it / kEPB;
+      if (ll >= nvalid || !row(r.done(), ll)) continue;
+      p.ring[(((size_t)(env0 + ll) * P) * TE_RING_DEPTH + (size_t)e) * (size_t)p.entry_words] = 0u;
+    }
+  }
+}
+
+}  // namespace te
