@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
       if (p.push) own_ok = ((armed >> ob) & 1u) != 0u;            // pushed by ring_push_kernel iff the observer is armed
       else own_ok = (int)load_fresh(own) == step;                 // te_observe_stacked: whatever the ring holds
       if (own_ok) {
-        const int cnt = (int)load_fresh(own + 1);
+        const int cnt = min((int)load_fresh(own + 1), r.F);   // (a ring that came in through te_set_state cannot overrun the list)
         for (int k = 0; k < cnt; ++k) {
           const te_w4 f = load_fresh4(own + TE_RING_HEADER_WORDS + 4 * k);
           const float thv = __uint_as_float(f.y), phv = __uint_as_float(f.z);
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
         const V3 po{__uint_as_float(o0.z), __uint_as_float(o0.w), __uint_as_float(o1.x)};
         const Q4 qo{__uint_as_float(o1.y), __uint_as_float(o1.z), __uint_as_float(o1.w), __uint_as_float(o2.x)};
         const M3 Rn = rotation(qn), Ro = rotation(inverse_of(qo));
-        const int cnt = (int)n0.y;
+        const int cnt = min((int)n0.y, r.F);
         const int base = r.list(1 + k);
         count = 0u;
         for (int f = 0; f < cnt; ++f) {
