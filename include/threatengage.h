@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define TE_ABI_VERSION 5
+#define TE_ABI_VERSION 5   /* layout of te_config / the state blob.  Added since without a layout change: the task presets 10-12, TE_REWARD_L5_C1,
+                              bit 1 of te_config.evaluation (TE_EVAL_ORIGIN_RULE) */
 
 /* ---- tasks (reference env class each one mirrors) ----------------------- */
 enum {
