@@ -326,7 +326,10 @@ int te_step(te_env* env, const float* actions, float* obs_lidar, float* obs_iner
  *                wins), padded with empty spheres, then shuffled;   obs_mask [N,6] u8 — 1 = a valid sphere.
  * Every armed wingman's snapshot (pose + the features of its own sphere) is pushed into a 10-deep ring per step;
  * the ring is part of the state blob.  terminal_* as in te_step.  te_observe_stacked is te_observe's counterpart
- * (after a reset every sphere is empty and every mask byte 0: there is no snapshot yet). */
+ * (after a reset every sphere is empty and every mask byte 0: there is no snapshot yet).  Both serve up to 37 drones per env (P <= 7;
+ * TE_TASK_LEVEL5_FUSION has 36); te_observe, the own-sphere observation, stops at 32.  Three launches after the sub-step kernel: the engage
+ * kernel, then one wave per (64-env chunk, wingman) pushing this step's ring entries, then one 5-wave workgroup per chunk for the
+ * observer's view (te_stackview.hpp). */
 int te_step_stacked(te_env* env, const float* actions, float* obs_stacked, uint8_t* obs_mask, float* obs_inertial,
                     float* obs_last_action, float* reward, uint8_t* done, int32_t* info, float* terminal_stacked,
                     uint8_t* terminal_mask, float* terminal_inertial, float* terminal_last_action, void* stream);
