@@ -42,9 +42,9 @@ D = dict(POS=0, QUAT=3, VEL=7, OMEGA=10, THROTTLE=13, PID_AV_I=17, PID_AV_E=20, 
          PENDING=48, ALLY_ACTION=48, ARMED=54, MUNITION=55, LAST_FIRED=56, NAV_STATE=57, KILLS=57)
 # word offsets inside an env record (TE_E_*)
 E = dict(STEP=0, MAX_STEP=1, ROUND=2, LAST_DIST=3, AGENT_KILLS=4, ALLIES_KILLS=5, DEADS=6, SNAP_MASK=7, EPISODE=8,
-         LAST_ACTION=9, PREV_SNAP_MIN=13, SNAP_MASK_HI=14)
+         LAST_ACTION=9, PREV_SNAP_MIN=13, SNAP_MASK_HI=14, INFO_WAVE=15)
 D_INT_WORDS = (54, 55, 56, 57)
-E_INT_WORDS = (0, 1, 2, 4, 5, 6, 7, 8, 14)
+E_INT_WORDS = (0, 1, 2, 4, 5, 6, 7, 8, 14, 15)
 
 
 class QuadParams(C.Structure):

@@ -511,6 +511,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     o.reward[env] = reward;
     o.done[env] = term ? 1 : 0;
     reinterpret_cast<int4*>(o.info)[env] = make_int4(agent_kills, allies_kills, deads, round);
+    ste(TE_E_INFO_WAVE, (uint32_t)round);   // (on_step_end below may start the next wave; an auto-reset puts 1 back)
   }
 
   TE_ESTAMP(6, 0);
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   if (to_terminal) {  // Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146): the env record here, the slots below
     episode += 1u; step = 0; max_step = c.max_step; round = 1;
     snap_mask = mask_after_spawn(1, true);
-    ste(TE_E_EPISODE, episode); ste(TE_E_STEP, 0u); ste(TE_E_MAX_STEP, (uint32_t)c.max_step); ste(TE_E_ROUND, 1u);
+    ste(TE_E_EPISODE, episode); ste(TE_E_STEP, 0u); ste(TE_E_MAX_STEP, (uint32_t)c.max_step); ste(TE_E_ROUND, 1u); ste(TE_E_INFO_WAVE, 1u);
     ste(TE_E_AGENT_KILLS, 0u); ste(TE_E_ALLIES_KILLS, 0u); ste(TE_E_DEADS, 0u);
     if (c.reward_model != TE_REWARD_L5_C1) stef(TE_E_LAST_DIST, c.dome_radius);
 #pragma unroll

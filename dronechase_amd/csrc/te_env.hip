@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(256) void wingman_info_kernel(Params p, int32_t* __
   const GView v{p.dstate, p.estate, p.D, p.Npad, env, P};
   int32_t* row = out + (size_t)i * 5;
   row[0] = v.gi(TE_D_KILLS, s); row[1] = v.gi(TE_D_ARMED, s) ? 1 : 0; row[2] = v.gi(TE_D_MUNITION, s);
-  row[3] = v.egi(TE_E_ROUND); row[4] = v.egi(TE_E_STEP);
+  row[3] = v.egi(TE_E_INFO_WAVE); row[4] = v.egi(TE_E_STEP);
 }
 __attribute__((visibility("default"))) int te_wingman_info(te_env* e, int32_t* wingman_info, void* stream) {
   if (!e || !wingman_info) return fail("te_wingman_info: null argument");

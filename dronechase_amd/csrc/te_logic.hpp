@@ -381,7 +381,7 @@ template <class V> TE_DEV void level4_setup_round(const te_config& c, const V& v
 template <class V> TE_DEV uint32_t level4_reset_record(const te_config& c, const V& v) {
   const uint32_t episode = (uint32_t)(v.egi(TE_E_EPISODE) + 1);
   v.esi(TE_E_EPISODE, (int)episode);
-  v.esi(TE_E_STEP, 0); v.esi(TE_E_MAX_STEP, c.max_step); v.esi(TE_E_ROUND, 1);
+  v.esi(TE_E_STEP, 0); v.esi(TE_E_MAX_STEP, c.max_step); v.esi(TE_E_ROUND, 1); v.esi(TE_E_INFO_WAVE, 1);
   v.esi(TE_E_AGENT_KILLS, 0); v.esi(TE_E_ALLIES_KILLS, 0); v.esi(TE_E_DEADS, 0);
   if (c.reward_model != TE_REWARD_L5_C1) v.esf(TE_E_LAST_DIST, c.dome_radius);   // Level5C1FusionTask's last_distance outlives every reset
 #pragma unroll
@@ -823,6 +823,7 @@ TE_DEV void level4_logic(const te_config& c, const SView& v, float4 action, cons
   o.reward[v.env] = reward;
   o.done[v.env] = term ? 1 : 0;
   reinterpret_cast<int4*>(o.info)[v.env] = make_int4(agent_kills, allies_kills, deads, round);
+  v.esi(TE_E_INFO_WAVE, round);
   emit_and_finish<FAM_LEVEL4>(c, v, step, term, A, o, [&]() {
     // on_step_end (:321-333): next wave when this one is cleared and a pursuer is alive
     if (!term && armed_invaders == 0 && armed_pursuers > 0) {

@@ -277,6 +277,8 @@ enum {
   TE_E_EPISODE = 8,      /* i32 episode counter (RNG stream selector) */
   TE_E_LAST_ACTION = 9,  /* 4 f32 */
   TE_E_PREV_SNAP_MIN = 13, /* f32 stage02: last_closest_pursuer_to_invader_distance */
+  TE_E_INFO_WAVE = 15,   /* i32 the wave as the step's compute_info saw it: BEFORE on_step_end may have started the next one (the environments read
+                            info between on_step_middle and on_step_end, evaluation_environment.py:178-186); te_wingman_info reports this */
   TE_E_SNAP_MASK_HI = 14,/* i32 bits 32..63 of the snapshot mask (more than 32 drones per env: TE_TASK_LEVEL5_DUMB has 37) */
   TE_ENV_WORDS = 16
 };

@@ -57,7 +57,7 @@ typedef struct {
 } ote_drone;
 
 typedef struct {
-  int32_t step, max_step, round;
+  int32_t step, max_step, round, info_wave;
   real last_dist;
   int32_t agent_kills, allies_kills, deads;
   uint64_t snap_mask; /* bit s = drone s armed when the offsets were last computed (blob: TE_E_SNAP_MASK + TE_E_SNAP_MASK_HI) */
@@ -1068,7 +1068,7 @@ static void level4_reset_env(ote_env* E, int e) {
   ote_envrec* er = &E->envs[e];
   er->episode += 1;
   /* on_episode_end: init_constants / init_globals / disarm_all */
-  er->step = 0; er->max_step = c->max_step; er->round = 1;
+  er->step = 0; er->max_step = c->max_step; er->round = 1; er->info_wave = 1;
   er->agent_kills = 0; er->allies_kills = 0; er->deads = 0;
   if (c->reward_model != TE_REWARD_L5_C1) er->last_dist = (real)c->dome_radius; /* Level5C1FusionTask's last_distance outlives every reset */
   for (int k = 0; k < 4; ++k) er->last_action[k] = 0;
@@ -1337,6 +1337,7 @@ static void level4_step_env(ote_env* E, int e, const float* action, float* lidar
 
   /* (5) info, (6) observation (agent = pursuer 0) */
   int32_t inf[4] = {er->agent_kills, er->allies_kills, er->deads, er->round};
+  er->info_wave = er->round; /* compute_info runs before on_step_end (evaluation_environment.py:178-186) */
   const int to_terminal = term && c->auto_reset; /* SB3: the terminal observation travels in `infos` */
   float* L = to_terminal && t_lidar ? t_lidar : lidar;
   float* In = to_terminal && t_inertial ? t_inertial : inertial;
@@ -1773,7 +1774,7 @@ OTE_API int ote_wingman_info(const ote_env* E, int32_t* out) {
     for (int p = 0; p < c->n_pursuers; ++p) {
       const ote_drone* d = &E->drones[(size_t)e * E->D + p];
       int32_t* row = out + ((size_t)e * c->n_pursuers + p) * 5;
-      row[0] = d->nav_state; row[1] = d->armed ? 1 : 0; row[2] = d->munition; row[3] = E->envs[e].round; row[4] = E->envs[e].step;
+      row[0] = d->nav_state; row[1] = d->armed ? 1 : 0; row[2] = d->munition; row[3] = E->envs[e].info_wave; row[4] = E->envs[e].step;
     }
   return 0;
 }
@@ -1891,7 +1892,7 @@ OTE_API int ote_get_state(const ote_env* E, uint32_t* dst) {
     const ote_envrec* r = &E->envs[e];
     uint32_t* w = base + (size_t)e * TE_ENV_WORDS;
     memset(w, 0, TE_ENV_WORDS * 4);
-    w[TE_E_STEP] = (uint32_t)r->step; w[TE_E_MAX_STEP] = (uint32_t)r->max_step; w[TE_E_ROUND] = (uint32_t)r->round;
+    w[TE_E_STEP] = (uint32_t)r->step; w[TE_E_MAX_STEP] = (uint32_t)r->max_step; w[TE_E_ROUND] = (uint32_t)r->round; w[TE_E_INFO_WAVE] = (uint32_t)r->info_wave;
     put_f(w, TE_E_LAST_DIST, &r->last_dist, 1);
     w[TE_E_AGENT_KILLS] = (uint32_t)r->agent_kills; w[TE_E_ALLIES_KILLS] = (uint32_t)r->allies_kills;
     w[TE_E_DEADS] = (uint32_t)r->deads; w[TE_E_SNAP_MASK] = (uint32_t)r->snap_mask; w[TE_E_SNAP_MASK_HI] = (uint32_t)(r->snap_mask >> 32); w[TE_E_EPISODE] = (uint32_t)r->episode;
@@ -1924,7 +1925,7 @@ OTE_API int ote_set_state(ote_env* E, const uint32_t* src) {
   for (int e = 0; e < E->cfg.n_envs; ++e) {
     ote_envrec* r = &E->envs[e];
     const uint32_t* w = base + (size_t)e * TE_ENV_WORDS;
-    r->step = (int32_t)w[TE_E_STEP]; r->max_step = (int32_t)w[TE_E_MAX_STEP]; r->round = (int32_t)w[TE_E_ROUND];
+    r->step = (int32_t)w[TE_E_STEP]; r->max_step = (int32_t)w[TE_E_MAX_STEP]; r->round = (int32_t)w[TE_E_ROUND]; r->info_wave = (int32_t)w[TE_E_INFO_WAVE];
     get_f(w, TE_E_LAST_DIST, &r->last_dist, 1);
     r->agent_kills = (int32_t)w[TE_E_AGENT_KILLS]; r->allies_kills = (int32_t)w[TE_E_ALLIES_KILLS];
     r->deads = (int32_t)w[TE_E_DEADS]; r->snap_mask = (uint64_t)w[TE_E_SNAP_MASK] | ((uint64_t)w[TE_E_SNAP_MASK_HI] << 32); r->episode = (int32_t)w[TE_E_EPISODE];

@@ -144,3 +144,57 @@ def compare_commands(g, after: Blob, which: int, still_armed=None, atol=2e-6):
                 assert after.i(e, s, "NAV_STATE") == nav[e, s - P], (e, s, which)
                 n_nav += 1
     return n_cmd, n_nav
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# tests/golden/evaluation_logic.npz (gen_evaluation_logic.py): Evaluation_Task with two behaviour-tree drivers through a whole step cycle.
+# TIME_IS_LIMITED is a property of the task object: the arenas split into two te_envs (cfg.max_step = 0: no limit).
+def evaluation_groups(g):
+    lim = g["limited"].astype(bool)
+    return [(np.flatnonzero(lim), True), (np.flatnonzero(~lim), False)]
+
+
+def evaluation_config(default_config, g, idx, limited):
+    assert np.array_equal(idx, np.arange(idx[0], idx[0] + len(idx)))     # contiguous: arena i is GLOBAL env i (its hit draws are keyed on it)
+    return default_config("evaluation", n_envs=len(idx), env_index_base=int(idx[0]), n_pursuers=int(g["P"]), n_invaders=int(g["I"]), n_rounds=int(g["I"]), munition=20,
+                          max_step=300 if limited else 0, substeps=0, observe_lag=0, motor_noise=0, auto_reset=0, seed=int(g["seed"]), dome_radius=float(g["dome"]))
+
+
+def evaluation_blob(g, idx, words: int) -> Blob:
+    sub = {k: (g[k][idx] if getattr(g[k], "ndim", 0) >= 1 and len(g[k]) == len(g["step"]) else g[k]) for k in g.files}
+    sub["last_dist"] = np.full(len(idx), 5.0); sub["kills"] = np.zeros((len(idx), 3), np.int32)
+    b = build_blob(sub, words)
+    n, P, I = len(idx), int(g["P"]), int(g["I"])
+    for e in range(n):
+        for j in range(I):
+            b.set_i(e, P + j, "NAV_STATE", int(sub["nav"][e, j]))
+        for p in range(P):
+            b.set_f(e, p, "FORMATION", sub["formation"][e, p])
+            b.set_i(e, p, "KILLS", int(g["kills"][idx[e], p]))          # lw_kills of the episode so far
+    return b, sub
+
+
+def compare_evaluation(sub, reward, done, rows, after: Blob):
+    """reward 0, termination, who is armed, guns, MAX_STEP, round and the info rows (lw_kills, lw_alive, lw_munitions, current_wave, step) of the
+    wingmen the reference lists (the armed ones)."""
+    n, P, I = len(sub["step"]), int(sub["P"]), int(sub["I"])
+    D = P + I
+    assert not np.asarray(reward).any()
+    assert np.array_equal(np.asarray(done).astype(bool), sub["done"].astype(bool)), np.flatnonzero(np.asarray(done).astype(bool) != sub["done"].astype(bool))
+    for e in range(n):
+        term = bool(sub["done"][e])
+        armed = np.array([after.i(e, s, "ARMED") for s in range(D)])
+        want = sub["armed_mid"][e] if term else sub["armed_after"][e]
+        assert np.array_equal(armed != 0, want != 0), (e, armed, want)
+        for p in range(P):
+            if sub["armed_mid"][e, p] and (term or sub["round_after"][e] == sub["round"][e]):
+                assert after.i(e, p, "MUNITION") == sub["munition_after"][e, p] and after.i(e, p, "LAST_FIRED") == sub["last_fired_after"][e, p], (e, p)
+            assert after.i(e, p, "KILLS") == sub["lw_kills_after"][e, p], (e, p)
+            if sub["info_rows"][e, p, 0] >= 0:
+                assert list(rows[e, p]) == list(sub["info_rows"][e, p]), (e, p, rows[e, p], sub["info_rows"][e, p])
+            else:
+                assert rows[e, p, 1] == 0, (e, p)        # not listed by the reference = not alive
+        assert after.ei(e, "MAX_STEP") == sub["max_step_after"][e], e
+        if not term:
+            assert after.ei(e, "ROUND") == sub["round_after"][e], e
+    return n

@@ -8,6 +8,7 @@ not with the oracle: te_set_state -> te_step / te_observe -> outputs + te_get_st
   level5_2bt_logic.npz   ... and of Level52BTEvaluationTask: two scripted wingmen, reward 0, fixed limit, kills per wingman (te_step + te_wingman_info)
   level5_c1_logic.npz    ... and of Level5C1FusionTask: agent + one scripted wingman, 4 -> 10 invaders, the minimal reward (te_step_stacked)
   level5_fusion_logic.npz ... and of Level5FusionTask: the RL agent + five scripted wingmen, 36 drones per env (te_step_stacked)
+  evaluation_logic.npz   Evaluation_Task with two "bt" drivers through the same cycle (te_step + te_wingman_info), with and without TIME_IS_LIMITED
   stage_logic.npz    stage02: L3Stage1.on_step_middle / on_step_end + level3 OffsetHandler / QuadcopterManager / Gun on 224 arenas;
                      stage01: PyflytL2EnviromentModifiedV2 reward / termination / replace_invader_if_close on 160 arenas
   lidar_math.npz     LidarMath binning of 1 000 body-frame vectors; add_features (closer wins) on 50 feature lists
@@ -181,6 +182,28 @@ def test_level5_2bt_logic_fixture_through_the_c_abi(golden):
     c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
     assert c1 >= 800 and s1 >= 500 and c2 >= 600 and s2 >= 500, (c1, s1, c2, s2)
     env.close()
+
+
+def test_evaluation_logic_fixture_through_the_c_abi(golden):
+    """Evaluation_Task with two behaviour-tree drivers (cfg.evaluation): termination with and without the time limit, kills per wingman and the
+    info rows through te_wingman_info, the commands of both trees and nine kamikaze state machines before and after the step."""
+    from dronechase_amd import default_config
+    g = golden("evaluation_logic.npz")
+    total = c1 = s1 = c2 = s2 = 0
+    for idx, limited in T.evaluation_groups(g):
+        cfg = T.evaluation_config(default_config, g, idx, limited)
+        env = _gpu(cfg)
+        n, D = cfg.n_envs, cfg.n_drones
+        blob, sub = T.evaluation_blob(g, idx, env.state_words())
+        _load(env, blob)
+        out = env.step(_zeros(n), terminal=False)
+        after = _state(env, n, D)
+        total += T.compare_evaluation(sub, out[-3].cpu().numpy(), out[-2].cpu().numpy(), env.wingman_info().cpu().numpy(), after)
+        a, b = T.compare_commands(sub, after, 1); c1 += a; s1 += b
+        env.step(_zeros(n), terminal=False)
+        a, b = T.compare_commands(sub, _state(env, n, D), 2); c2 += a; s2 += b
+        env.close()
+    assert total == len(g["step"]) and c1 >= 700 and s1 >= 400 and c2 >= 500 and s2 >= 350, (total, c1, s1, c2, s2)
 
 
 def test_stage02_logic_fixture_through_the_c_abi(golden):
