@@ -53,7 +53,9 @@ def test_kills_are_counted_per_wingman_and_survive_the_waves():
     assert rows[:, 0].tolist() == [0, 1] and rows[:, 1].tolist() == [1, 1] and rows[:, 2].tolist() == [20, 19]
     assert list(out["info"]) == [0, 1, 0, 1]                     # the classic info still says "an ally killed"
     b = load(env, cfg)
-    assert b.ei(0, "ROUND") == 2 and rows[0, 3] == 2 and rows[0, 4] == 1     # wave advanced in on_step_end; kills kept
+    # the wave advanced in on_step_end, AFTER compute_info ran (evaluation_environment.py:178-186): the info rows still say wave 1
+    # (pinned by tests/golden/evaluation_logic.npz); kills kept
+    assert b.ei(0, "ROUND") == 2 and rows[0, 3] == 1 and rows[0, 4] == 1
     assert b.i(0, 1, "KILLS") == 1 and b.i(0, 0, "KILLS") == 0
     # a second kill by the agent in the next wave: place one invader next to it, park the other far away but inside
     b.place(0, 2, (0.5, 0, 3)); b.hover_ready(0, 2, cfg)
