@@ -198,3 +198,21 @@ def compare_evaluation(sub, reward, done, rows, after: Blob):
         if not term:
             assert after.ei(e, "ROUND") == sub["round_after"][e], e
     return n
+
+
+def compare_reset(g, after: Blob, per_wingman_kills=False):
+    """Env.reset -> Task.on_reset of the fixtures made by gen_level5_logic.py: who is armed (every wingman, the first round's invaders), guns
+    (full munition, cooldown over), MAX_STEP, round 1, the counters, last_closest_distance (Level5C1FusionTask's last_distance survives), the
+    invaders' state machines back in WaitState, step 0."""
+    n, P, I = len(g["step"]), int(g["P"]), int(g["I"])
+    for e in range(n):
+        assert [int(after.i(e, s, "ARMED") != 0) for s in range(P + I)] == list(g["reset_armed"][e]), e
+        assert [after.i(e, p, "MUNITION") for p in range(P)] == list(g["reset_munition"][e]) and [after.i(e, p, "LAST_FIRED") for p in range(P)] == list(g["reset_last_fired"][e]), e
+        assert after.ei(e, "MAX_STEP") == g["reset_max_step"][e] and after.ei(e, "ROUND") == g["reset_round"][e] and after.ei(e, "STEP") == 0, e
+        if per_wingman_kills:
+            assert [after.i(e, p, "KILLS") for p in range(P)] == list(g["reset_kills"][e, :P]) and after.ei(e, "DEADS") == g["reset_kills"][e, 2], e
+        else:
+            assert [after.ei(e, "AGENT_KILLS"), after.ei(e, "ALLIES_KILLS"), after.ei(e, "DEADS")] == list(g["reset_kills"][e]), e
+        np.testing.assert_allclose(after.ef(e, "LAST_DIST")[0], g["reset_last_dist"][e], rtol=2e-6, atol=1e-5)
+        assert all(after.i(e, P + j, "NAV_STATE") == g["reset_nav"][e, j] for j in range(I) if g["reset_armed"][e, P + j]), e
+    return n

@@ -198,7 +198,8 @@ def main(kind="level5", n=256):
     arenas = make_arenas(rng, n)
     keys = ("armed", "pos", "vel", "munition", "last_fired", "step", "max_step", "round", "last_dist", "kills", "nav", "formation", "cmd1", "nav1", "counts",
             "reward", "done", "info", "armed_mid", "armed_after", "munition_after", "last_fired_after", "max_step_after", "kills_after", "last_dist_after",
-            "round_after", "shots_fired", "cmd2", "nav2", "comparable", "closest_ally", "target")
+            "round_after", "shots_fired", "cmd2", "nav2", "comparable", "closest_ally", "target",
+            "reset_armed", "reset_munition", "reset_last_fired", "reset_max_step", "reset_round", "reset_kills", "reset_last_dist", "reset_nav")
     rec = {k: [] for k in keys}
 
     def commands(drones):
@@ -292,14 +293,25 @@ def main(kind="level5", n=256):
             task.on_step_start()                            # ---- commands of step t+1
             cmd2 = commands(drones)
             nav2 = np.array([STATES.index(task.kamikaze_navigator.fetch_state(drones[P + j]).name) if armed_after[P + j] else -1 for j in range(I)], np.int32)
-        for k, v in dict(armed=a["armed"], pos=a["pos"], vel=a["vel"], munition=a["munition"], last_fired=a["last_fired"], step=step, max_step=a["max_step"],
+        post = dict(max_step_after=task.MAX_STEP, kills_after=[task.agent_kills, task.allies_kills, task.deads],
+                    last_dist_after=task.last_distance if kind == "level5_c1" else task.last_closest_distance, round_after=task.current_round)
+        # ---- Env.reset -> Task.on_reset (on_episode_end + on_episode_start) on whatever the cycle left: the bookkeeping a reset must restore
+        np.random.seed(1000 + ai)
+        task.on_reset()
+        if hasattr(task, "kills_per_drone"):
+            rk = [task.kills_per_drone[100]["kills"], task.kills_per_drone[101]["kills"], task.deads]
+        else:
+            rk = [task.agent_kills, task.allies_kills, task.deads]
+        reset = dict(reset_armed=[int(drones[s].armed) for s in range(D)], reset_munition=[drones[p].gun.munition for p in range(P)],
+                     reset_last_fired=[int(drones[p].gun.last_fired_step) for p in range(P)], reset_max_step=task.MAX_STEP, reset_round=task.current_round,
+                     reset_kills=rk, reset_last_dist=task.last_distance if kind == "level5_c1" else task.last_closest_distance,
+                     reset_nav=[STATES.index(task.kamikaze_navigator.fetch_state(drones[P + j]).name) for j in range(I)])
+        for k, v in dict(reset, armed=a["armed"], pos=a["pos"], vel=a["vel"], munition=a["munition"], last_fired=a["last_fired"], step=step, max_step=a["max_step"],
                          round=a["round"], last_dist=a["last_dist"], kills=a["kills"], nav=a["nav"], formation=a["formation"], cmd1=cmd1, nav1=nav1,
                          counts=np.array(seen["c"] if len(seen["c"]) else (0, 0, 0, 0, 0), np.int32), reward=float(reward), done=int(bool(done)),
                          info=[info["agent_kills"], info["allies_kills"], info["deads"], info["current_wave"]], armed_mid=seen["armed_mid"],
-                         armed_after=armed_after, munition_after=mun_after, last_fired_after=lf_after, max_step_after=task.MAX_STEP,
-                         kills_after=[task.agent_kills, task.allies_kills, task.deads],
-                         last_dist_after=task.last_distance if kind == "level5_c1" else task.last_closest_distance,
-                         round_after=task.current_round, shots_fired=fired, cmd2=cmd2, nav2=nav2, comparable=comparable,
+                         armed_after=armed_after, munition_after=mun_after, last_fired_after=lf_after, **post,
+                         shots_fired=fired, cmd2=cmd2, nav2=nav2, comparable=comparable,
                          closest_ally=ca_slot, target=slot_of(tgt) if tgt != -1 else -1).items():
             rec[k].append(v)
     assert not G.TOUCHED, G.TOUCHED

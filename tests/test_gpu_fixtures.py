@@ -98,6 +98,8 @@ def test_level5_logic_fixture_through_the_c_abi(golden):
     env.step_stacked(_zeros(n), terminal=False)
     c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
     assert c1 >= 900 and s1 >= 250 and c2 >= 700 and s2 >= 250, (c1, s1, c2, s2)
+    env.reset()
+    assert T.compare_reset(g, _state(env, n, D), per_wingman_kills=False) == n
     env.close()
 
 
@@ -116,6 +118,8 @@ def test_level5_dumb_logic_fixture_through_the_c_abi(golden):
     env.step_students()
     c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
     assert c1 >= 1000 and s1 >= 250 and c2 >= 800 and s2 >= 250, (c1, s1, c2, s2)
+    env.reset()
+    assert T.compare_reset(g, _state(env, n, D), per_wingman_kills=False) == n
     env.close()
 
 
@@ -159,6 +163,8 @@ def test_level5_fusion_logic_fixture_through_the_c_abi(golden):
     env.step_stacked(_zeros(n), terminal=False)
     c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
     assert c1 >= 900 and s1 >= 250 and c2 >= 700 and s2 >= 250, (c1, s1, c2, s2)
+    env.reset()
+    assert T.compare_reset(g, _state(env, n, D), per_wingman_kills=False) == n
     env.close()
 
 
@@ -181,6 +187,8 @@ def test_level5_2bt_logic_fixture_through_the_c_abi(golden):
     env.step(_zeros(n), terminal=False)
     c2, s2 = T.compare_commands(g, _state(env, n, D), 2)
     assert c1 >= 800 and s1 >= 500 and c2 >= 600 and s2 >= 500, (c1, s1, c2, s2)
+    env.reset()
+    assert T.compare_reset(g, _state(env, n, D), per_wingman_kills=True) == n
     env.close()
 
 

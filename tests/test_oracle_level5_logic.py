@@ -38,6 +38,8 @@ def test_oracle_reproduces_the_reference_level5_step_cycle(g, prec):
     orc.step_stacked(zeros, terminal=False)
     c2, s2 = T.compare_commands(g, Blob(orc.get_state(), n, D), 2)
     assert c1 >= 900 and s1 >= 250 and c2 >= 700 and s2 >= 250, (c1, s1, c2, s2)
+    orc.reset()
+    assert T.compare_reset(g, Blob(orc.get_state(), n, D)) == n
 
 
 # ---------------------------------------------------------------------------------------------------------------- Level5DumbMultiObjectTask
@@ -73,6 +75,8 @@ def test_oracle_reproduces_the_reference_dumb_multiobject_step_cycle(gd, prec):
     orc.step_students()
     c2, s2 = T.compare_commands(g, Blob(orc.get_state(), n, D), 2)
     assert c1 >= 1000 and s1 >= 250 and c2 >= 800 and s2 >= 250, (c1, s1, c2, s2)
+    orc.reset()
+    assert T.compare_reset(g, Blob(orc.get_state(), n, D)) == n
 
 
 # ---------------------------------------------------------------------------------------------------------------- Level52BTEvaluationTask
@@ -112,6 +116,8 @@ def test_oracle_reproduces_the_reference_2bt_evaluation_step_cycle(g2, prec):
     orc.step(zeros, terminal=False)
     c2, s2 = T.compare_commands(g, Blob(orc.get_state(), n, D), 2)
     assert c1 >= 800 and s1 >= 500 and c2 >= 600 and s2 >= 500, (c1, s1, c2, s2)
+    orc.reset()
+    assert T.compare_reset(g, Blob(orc.get_state(), n, D), per_wingman_kills=True) == n
 
 
 # ---------------------------------------------------------------------------------------------------------------- Level5C1FusionTask
@@ -149,6 +155,12 @@ def test_oracle_reproduces_the_reference_c1_fusion_step_cycle(gc, prec):
     orc.step_stacked(zeros, terminal=False)
     c2, s2 = T.compare_commands(g, Blob(orc.get_state(), n, D), 2)
     assert c1 >= 300 and s1 >= 250 and c2 >= 250 and s2 >= 200, (c1, s1, c2, s2)
+    final = Blob(orc.get_state(), n, D)
+    orc.reset()
+    back = Blob(orc.get_state(), n, D)
+    g_reset = {k: g[k] for k in g.files}
+    g_reset["reset_last_dist"] = np.array([final.ef(e, "LAST_DIST")[0] for e in range(n)])   # the once-only last_distance: whatever the env holds stays
+    assert T.compare_reset(g_reset, back) == n
 
 
 def test_c1_last_distance_outlives_a_reset(gc):
@@ -193,3 +205,5 @@ def test_oracle_reproduces_the_reference_fusion_step_cycle(gf, prec):
     orc.step_stacked(zeros, terminal=False)
     c2, s2 = T.compare_commands(g, Blob(orc.get_state(), n, D), 2)
     assert c1 >= 900 and s1 >= 250 and c2 >= 700 and s2 >= 250, (c1, s1, c2, s2)
+    orc.reset()
+    assert T.compare_reset(g, Blob(orc.get_state(), n, D)) == n
