@@ -31,12 +31,18 @@ __global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
   const V3 me{__uint_as_float(snap(sr.pos() + 0 * D + pp)), __uint_as_float(snap(sr.pos() + 1 * D + pp)), __uint_as_float(snap(sr.pos() + 2 * D + pp))};
   const Q4 q = quat_of_euler(V3{__uint_as_float(snap(sr.euler() + 0 * P + pp)), __uint_as_float(snap(sr.euler() + 1 * P + pp)), __uint_as_float(snap(sr.euler() + 2 * P + pp))});
   const Q4 qi = inverse_of(q);
+  // Slots at or above `hi` are disarmed in every env of the wave (a round arms the first invaders of the table: 5 to 15 of level5_fusion's 30 in
+  // its first rounds): the compile-time loops below skip them on a scalar test (ring_push_kernel<37>: 307 -> us per launch)
+  int top = 64 - __clzll((unsigned long long)A);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off));
+  const int hi = __builtin_amdgcn_readfirstlane(top);
   // ---- the sphere of wingman pp: (r_hat, theta, phi, cell) of every other armed drone
   float rh[DM], th[DM], ph[DM]; uint32_t cell[DM];
 #pragma unroll
   for (int j = 0; j < DM; ++j) {
     cell[j] = 0xFFFFFFFFu; rh[j] = 1.0f; th[j] = 0.0f; ph[j] = 0.0f;
-    if (j < D && j != pp && ((A >> j) & 1u)) {
+    if (j < hi && j != pp && ((A >> j) & 1u)) {
       const V3 pj{__uint_as_float(snap(sr.pos() + 0 * D + j)), __uint_as_float(snap(sr.pos() + 1 * D + j)), __uint_as_float(snap(sr.pos() + 2 * D + j))};
       const V3 local = rotate_by(qi, sub(pj, me));
       int cl;
@@ -50,12 +56,13 @@ __global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
   uint32_t n = 0u;
 #pragma unroll
   for (int j = 0; j < DM; ++j) {
+    if (j >= hi) continue;   // wave-uniform
     const bool claim = cell[j] != 0xFFFFFFFFu && rh[j] < 1.0f;
     bool lead = claim;
     float br = rh[j], bt = th[j], bp = ph[j]; int bw = j;
 #pragma unroll
     for (int k = 0; k < DM; ++k) {
-      if (k == j) continue;
+      if (k == j || k >= hi) continue;
       const bool same = claim && cell[k] == cell[j] && rh[k] < 1.0f;   // cell[k] == 0xFFFFFFFF never equals a claimed cell
       if (same && k < j) lead = false;
       if (same && (rh[k] < br || (rh[k] == br && k < bw))) { br = rh[k]; bt = th[k]; bp = ph[k]; bw = k; }
