@@ -1074,6 +1074,7 @@ __attribute__((visibility("default"))) int te_reset(te_env* e, const uint8_t* en
   if (host_io(e) && env_mask) {   // the mask is a host array: staged
     hipStream_t st = (hipStream_t)stream;
     TE_H2D(e->hs.mask, env_mask, (size_t)e->p.N);
+    TE_HIP(hipStreamSynchronize(st));   // the caller may reuse or free its (possibly pinned) array as soon as the call returns
     env_mask = e->hs.mask;
   }
   const int blocks = (e->p.N + 255) / 256;
@@ -1468,6 +1469,7 @@ __attribute__((visibility("default"))) int te_set_state(te_env* e, const void* s
   if (host_io(e)) {   // src is a host buffer
     hipStream_t st = (hipStream_t)stream;
     TE_H2D(e->hs.blob, src_device, need * 4);
+    TE_HIP(hipStreamSynchronize(st));   // the caller may reuse or free its (possibly pinned) blob as soon as the call returns
     src_device = e->hs.blob;
   }
   hipLaunchKernelGGL(blob_to_planes, dim3(1024), dim3(256), 0, (hipStream_t)stream, e->p, (const uint32_t*)src_device);

@@ -23,20 +23,23 @@ __global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
   const SnapRows sr{D, P};
   const int chunk = blockIdx.x / P, pp = blockIdx.x - chunk * P;
   const int lane = threadIdx.x, env = chunk * kEPB + lane;
-  if (env >= p.N) return;
+  // env < Npad always (the planes are padded to whole chunks), so every lane may read; the lanes beyond N contribute nothing
   auto snap = [&](int w) { return p.snap[(size_t)w * p.Npad + env]; };
-  const uint64_t A = (uint64_t)snap(sr.armed()) | ((uint64_t)snap(sr.armed_hi()) << 32);
-  if (!((A >> pp) & 1u)) return;   // a disarmed wingman publishes nothing: its ring keeps the older entries
+  const bool live = env < p.N;
+  const uint64_t A = live ? ((uint64_t)snap(sr.armed()) | ((uint64_t)snap(sr.armed_hi()) << 32)) : 0ull;
+  const bool mine = live && ((A >> pp) & 1u);
+  // Slots at or above `hi` are disarmed in every publishing env of the wave (a round arms the first invaders of the table: 5 to 15 of
+  // level5_fusion's 30 in its first rounds): the compile-time loops below skip them on a scalar test.  The butterfly runs BEFORE any lane
+  // leaves: __shfl_xor is ds_bpermute under EXEC, and an inactive source lane would hand back 0 instead of relaying its partial maximum.
+  int top = mine ? 64 - __clzll((unsigned long long)A) : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off));
+  const int hi = __builtin_amdgcn_readfirstlane(top);
+  if (!mine) return;   // a disarmed wingman publishes nothing: its ring keeps the older entries
   const int step = (int)snap(sr.step());
   const V3 me{__uint_as_float(snap(sr.pos() + 0 * D + pp)), __uint_as_float(snap(sr.pos() + 1 * D + pp)), __uint_as_float(snap(sr.pos() + 2 * D + pp))};
   const Q4 q = quat_of_euler(V3{__uint_as_float(snap(sr.euler() + 0 * P + pp)), __uint_as_float(snap(sr.euler() + 1 * P + pp)), __uint_as_float(snap(sr.euler() + 2 * P + pp))});
   const Q4 qi = inverse_of(q);
-  // Slots at or above `hi` are disarmed in every env of the wave (a round arms the first invaders of the table: 5 to 15 of level5_fusion's 30 in
-  // its first rounds): the compile-time loops below skip them on a scalar test (ring_push_kernel<37>: 307 -> us per launch)
-  int top = 64 - __clzll((unsigned long long)A);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off));
-  const int hi = __builtin_amdgcn_readfirstlane(top);
   // ---- the sphere of wingman pp: (r_hat, theta, phi, cell) of every other armed drone
   float rh[DM], th[DM], ph[DM]; uint32_t cell[DM];
 #pragma unroll

@@ -145,6 +145,27 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
             torch.cuda.current_stream(self.backend.device).synchronize()
         return [h.numpy() for h in outs]
 
+    def _snapshot_async(self, tensors):
+        """Enqueue non-blocking copies of small device tensors into fresh pinned blocks and record an event; the returned callable waits for
+        that event (not for the stream) and hands out the numpy arrays."""
+        import torch
+
+        if all(t.device.type == "cpu" for t in tensors):          # stub backends of the CPU tests
+            held = [t.detach().clone() for t in tensors]
+            return lambda: [h.numpy() for h in held]
+        held = []
+        for t in tensors:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t.detach(), non_blocking=True)
+            held.append(h)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.backend.device))
+
+        def wait():
+            ev.synchronize()
+            return [h.numpy() for h in held]
+        return wait
+
     def _obs_keys(self):
         return ("stacked_spheres", "validity_mask", "inertial_data", "last_action") if self.stacked else ("lidar", "inertial_data", "last_action")
 
@@ -188,12 +209,15 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
         tbuf = ({"stacked_spheres": b.t_stacked, "validity_mask": b.t_mask.bool()} if self.stacked else {"lidar": b.t_lidar})
         tbuf.update({"inertial_data": b.t_inertial, "last_action": b.t_last_action})
         if self.output == "torch":
-            # nothing leaves the device here: infos read done / info (one small copy, which drains the stream) when somebody indexes them
+            # The observations stay on the device.  done / info (17 bytes per env) are the backend's persistent buffers, which the NEXT step
+            # overwrites: their values of THIS step are copied now, asynchronously, into fresh pinned memory behind an event; an info indexed
+            # later (a logger that drains afterwards, an asynchronous collector) waits for that event only and reads this step's values.
             host = {}
+            fetch = self._snapshot_async([info, done])
 
             def both():
                 if not host:
-                    host["info"], d = self._to_host([info, done])
+                    host["info"], d = fetch()
                     host["done"] = d.astype(bool)
                 return host
             infos = LazyInfos(lambda: both()["info"], lambda: both()["done"], tbuf)

@@ -200,3 +200,87 @@ def test_level5_vecenv_and_single_env_surface(cls_name):
     assert o["validity_mask"].sum() >= 1 and trunc is False
     assert info == {} if cls_name == "Level5C1FusionEnvironment" else set(info) >= {"agent_kills", "allies_kills", "deads", "current_wave"}
     e.close()
+
+
+@pytest.mark.parametrize("task", ["level5", "level5_fusion", "level5_dumb"])
+def test_heterogeneous_chunk_ring_matches_lds_fallback_and_oracle(task, monkeypatch):
+    """A chunk whose lanes differ: wingmen dead in scattered envs, a different highest armed slot per env, N not a multiple of 64.
+    ring_push_kernel reduces the wave's highest armed slot over lanes of which some publish nothing (the round-2 butterfly ran AFTER those
+    lanes had left and lost features): the default register kernels must agree bit for bit with the LDS fallback (TE_STACKED=lds) and,
+    within the usual tolerances, with the oracle."""
+    torch = _gpu()
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    from oracle import te_oracle as O
+    from tests._blob import Blob
+    N = 200
+    cfg = default_config(task, n_envs=N, motor_noise=0, seed=21)
+    P, D = int(cfg.n_pursuers), int(cfg.n_drones)
+    students = task == "level5_dumb"
+    g = BatchedEnv(cfg, "cuda:0")
+    monkeypatch.setenv("TE_STACKED", "lds")
+    h = BatchedEnv(cfg, "cuda:0")
+    monkeypatch.delenv("TE_STACKED")
+    o = O.OracleEnv(cfg, "f32", threads=4)
+    g.reset()
+    for t in range(4):   # a few ordinary steps: the ring holds entries of every wingman
+        if students: g.step_students()
+        else: g.step_stacked(g.random_actions(4, t))
+    b = Blob(g.get_state().cpu().numpy().view(np.uint32), N, D)
+    rng = np.random.default_rng(5)
+    tops = set()
+    for e in range(N):
+        # the agent (slot 0) lives except in a few student envs (level5_dumb survives its death); every other wingman dies with p = 0.4
+        for p in range(0 if students else 1, P):
+            if rng.random() < (0.15 if p == 0 else 0.4):
+                b.set_i(e, p, "ARMED", 0)
+                for name in ("VEL", "OMEGA"): b.set_f(e, p, name, [0, 0, 0])
+        if not any(b.i(e, p, "ARMED") for p in range(P)):
+            b.set_i(e, P - 1, "ARMED", 1)
+        # invaders: an arbitrary subset of the table per env, so the highest armed slot differs from lane to lane
+        k = int(rng.integers(1, D - P + 1))
+        for d in range(P, D):
+            want = (d - P) < k and rng.random() < 0.7
+            if want and not b.i(e, d, "ARMED"):
+                u = rng.normal(size=3); u /= np.linalg.norm(u)
+                b.place(e, d, (u * rng.uniform(1.5, 5.5)).astype(np.float32)); b.hover_ready(e, d, cfg)
+            elif not want and b.i(e, d, "ARMED"):
+                b.set_i(e, d, "ARMED", 0)
+                for name in ("VEL", "OMEGA"): b.set_f(e, d, name, [0, 0, 0])
+        if not any(b.i(e, d, "ARMED") for d in range(P, D)):
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            b.place(e, P, (u * 3.0).astype(np.float32)); b.hover_ready(e, P, cfg)
+        b.refresh_snapshot(e)
+        tops.add(b.armed_mask(e).bit_length())
+    assert len(tops) >= 4                                   # the lanes of a chunk really have different highest armed slots
+    w = torch.from_numpy(b.w.view(np.int32)).cuda()
+    g.set_state(w); h.set_state(w); o.set_state(b.w)
+    dirty = np.zeros(N, bool)
+    for t in range(4, 7):
+        if students:
+            ro = o.step_students(); rg = g.step_students(); rh = h.step_students()
+            so, mo, do = ro[0], ro[1], ro[6]
+        else:
+            a = o.random_actions(4, t); ta = torch.from_numpy(a).cuda()
+            ro = o.step_stacked(a); rg = g.step_stacked(ta); rh = h.step_stacked(ta)
+            so, mo, do = ro[0], ro[1], ro[5]
+        torch.cuda.synchronize()
+        for x, y in zip(rg, rh):
+            assert torch.equal(x, y), t                      # register kernels == LDS fallback, bit for bit
+        wg, wh = g.get_state(), h.get_state()
+        rg_ring, rh_ring = o.ring(wg.cpu().numpy().view(np.uint32)), o.ring(wh.cpu().numpy().view(np.uint32))
+        live = rg_ring[..., 0] != 0
+        np.testing.assert_array_equal(rg_ring[..., 0], rh_ring[..., 0]); np.testing.assert_array_equal(rg_ring[live][:, 1], rh_ring[live][:, 1])
+        dirty |= (o.stack_margins() < CELL_MARGIN) | (o.state_margins() < MARGIN)
+        sg, mg = rg[0].cpu().numpy(), rg[1].cpu().numpy()
+        done = do != 0
+        cmp_ = ~dirty & ~done                                 # auto-reset envs show the reset observation on both sides; checked elsewhere
+        assert (mg[cmp_] == mo[cmp_]).all(), t
+        assert np.abs(sg[cmp_] - so[cmp_]).max() <= OBS_TOL, t
+        ro_ring = o.ring()
+        ok = ~dirty
+        np.testing.assert_array_equal(rg_ring[ok][..., 0], ro_ring[ok][..., 0])
+        lv = ro_ring[ok][..., 0] != 0
+        np.testing.assert_array_equal(rg_ring[ok][lv][:, 1], ro_ring[ok][lv][:, 1])     # kept features per entry: what the bug lost
+    assert (~dirty).sum() > N // 2
+    g.close(); h.close(); o.close()

@@ -112,6 +112,55 @@ def test_torch_output_reads_nothing_back_until_an_info_is_indexed():
     assert all(type(di[i]["deads"]) is int for i in range(n))
 
 
+def test_lazy_infos_hold_the_values_of_their_own_step():
+    """The backend's done / info tensors are persistent buffers that every step overwrites IN PLACE: infos indexed only after the next step
+    has been issued (a logger that drains later) must still show the step that produced them."""
+    import torch
+    from dronechase_amd.vec_env import ThreatEngageVecEnv
+
+    class InPlace(StubBackend):
+        def step(self, actions, terminal=True):
+            self.calls.append("step")
+            self.last_action.copy_(actions); self.reward.copy_(actions[:, 3])
+            self.done.copy_((actions[:, 0] > 0.5).to(torch.uint8))
+            self.info.copy_((actions[:, 1:2] * 100).to(torch.int32).expand(-1, 4))
+            return self.lidar, self.inertial, self.last_action, self.reward, self.done, self.info
+
+    n = 4
+    v = ThreatEngageVecEnv("stage03", num_envs=n, backend=InPlace(n), output="torch", infos="lazy")
+    v.reset()
+    a = torch.zeros((n, 4)); a[3, 0] = 1.0; a[:, 1] = 0.07
+    b = torch.zeros((n, 4)); b[1, 0] = 1.0; b[:, 1] = 0.09
+    _, _, _, first = v.step(a)
+    _, _, _, second = v.step(b)
+    assert first[0]["agent_kills"] == 7 and "terminal_observation" in first[3] and "terminal_observation" not in first[1]
+    assert second[0]["agent_kills"] == 9 and "terminal_observation" in second[1] and "terminal_observation" not in second[3]
+
+
+@pytest.mark.gpu
+def test_lazy_infos_on_gpu_survive_the_next_step():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from dronechase_amd.vec_env import ThreatEngageVecEnv
+    n = 256
+    v = ThreatEngageVecEnv("stage03", num_envs=n, seed=4, max_step=6, output="torch", infos="lazy")
+    w = ThreatEngageVecEnv("stage03", num_envs=n, seed=4, max_step=6, output="torch", infos="dicts")
+    v.reset(); w.reset()
+    held, eager = [], []
+    for s in range(16):
+        a = v.backend.random_actions(9, s)
+        held.append(v.step(a)[3]); eager.append(w.step(a)[3])
+    saw_done = 0
+    for lazy, now in zip(held, eager):          # the lazy infos are only read here, 1..16 steps late
+        for e in range(n):
+            assert {k: lazy[e][k] for k in ("agent_kills", "allies_kills", "deads", "current_wave")} == {k: now[e][k] for k in ("agent_kills", "allies_kills", "deads", "current_wave")}
+            assert ("terminal_observation" in lazy[e]) == ("terminal_observation" in now[e])
+            saw_done += "terminal_observation" in now[e]
+    assert saw_done >= n
+    v.close(); w.close()
+
+
 @pytest.mark.gpu
 def test_vecenv_on_gpu_matches_batched_env():
     import torch
