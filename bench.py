@@ -8,9 +8,11 @@
 
 One "step" = one env.step() (te_step: two HIP kernels) of every environment of the rank's shard on one batch of
 synthetic actions (dir ~ U(-1,1)^3, mag ~ U(0,1), Philox; mirrors apps/threatengage_runner/interactive/analyse.py:55-59)
-that te_random_actions left in HBM before the timed region.  Environments shard across ranks with no data-path collective
-(weak scaling: --envs-per-gpu is fixed); RNG is keyed on the GLOBAL env index.  Rank 0 prints ONE JSON
-line.  Inputs and outputs stay resident in HBM for the whole timed region.
+that te_random_actions left in HBM before the timed region.  Environments shard across ranks with no data-path collective;
+RNG is keyed on the GLOBAL env index.  The headline is the configuration BASELINE.json's metric names: 65 536 stage03 envs IN
+TOTAL (--total-envs), i.e. 65 536 / N per GPU — strong scaling; with N > 1 the line also carries a `weak_scaling` block
+(65 536 envs PER GPU, the size one MI355X is efficient at).  --envs-per-gpu fixes the shard size instead (then `scaling` says
+"weak").  Rank 0 prints ONE JSON line.  Inputs and outputs stay resident in HBM for the whole timed region.
 """
 from __future__ import annotations
 
@@ -39,7 +41,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--task", default="stage03", help="stage01 | stage02 | exp02 | stage03 (= exp03) | exp04 | level5 (stacked observation) | exp05 (ally observed + driven by the caller every step) | evaluation | level5_2bt")
-    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--total-envs", type=int, default=65536, help="envs of the whole job, split evenly over the ranks (BASELINE.json: 65 536)")
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="fix the shard size instead of the total (weak scaling)")
+    ap.add_argument("--no-weak-block", action="store_true", help="N > 1: skip the extra 65 536-envs-per-GPU measurement")
     ap.add_argument("--n-invaders", type=int, default=0, help="override I (stage02 with 8 invaders: --n-invaders 8)")
     ap.add_argument("--no-noise", action="store_true", help="motor noise off (parity runs); default on")
     ap.add_argument("--seed", type=int, default=0)
@@ -136,231 +140,236 @@ def main():
     overrides = dict(motor_noise=0 if args.no_noise else 1, seed=args.seed)
     if args.n_invaders:
         overrides["n_invaders"] = args.n_invaders
-    n_local = args.envs_per_gpu
-    cfg = default_config(args.task, n_envs=n_local, env_index_base=rank * n_local, **overrides)
-    env = BatchedEnv(cfg, device)
-    # The inputs of the timed region are resident in HBM when it starts (one [N,4] action batch per step, generated on
-    # the device by te_random_actions beforehand): the timed loop is te_step only.  Above 4 GiB of actions the batches
-    # are generated step by step inside the loop instead.
-    n_total = args.steps + args.warmup
-    pregen = n_total * n_local * 16 <= (4 << 30)
-    actions = torch.empty((n_total if pregen else 1, n_local, 4), dtype=torch.float32, device=device)
-    if pregen:
-        for i in range(n_total):
-            env.random_actions(args.action_seed, i, out=actions[i])
+    use_events = not args.no_profile_events
+    markers = os.environ.get("TE_PROF") == "markers"
 
-    step_fn = env.step_stacked if cfg.stacked_obs else env.step   # level5: te_step_stacked (third launch: stacked_kernel)
-    # exp05: one env.step = te_observe_ally -> driver -> te_set_ally_actions -> te_step.  The driver here is synthetic
-    # (pre-generated random actions: the policy network is the caller's, not this library's), the observation is built
-    # every step all the same.
-    external = int(cfg.ally_policy) == 3
-    ally_actions = None
-    if external:
-        ally_actions = torch.empty((n_total if pregen else 1, n_local, 4), dtype=torch.float32, device=device)
+    def measure(n_local: int, headline_only: bool, scaling: str) -> dict:
+        """Everything measured on one shard size: the headline window, and (unless headline_only) the steady-state and all-armed regimes.
+        Returns the JSON line's fields (meaningful on rank 0)."""
+        cfg = default_config(args.task, n_envs=n_local, env_index_base=rank * n_local, **overrides)
+        env = BatchedEnv(cfg, device)
+        # The inputs of the timed region are resident in HBM when it starts (one [N,4] action batch per step, generated on
+        # the device by te_random_actions beforehand): the timed loop is te_step only.  Above 4 GiB of actions the batches
+        # are generated step by step inside the loop instead.
+        n_total = args.steps + args.warmup
+        pregen = n_total * n_local * 16 <= (4 << 30)
+        actions = torch.empty((n_total if pregen else 1, n_local, 4), dtype=torch.float32, device=device)
         if pregen:
             for i in range(n_total):
-                env.random_actions(args.action_seed + 1000, i, out=ally_actions[i])
+                env.random_actions(args.action_seed, i, out=actions[i])
 
-    def one_step(i: int):
+        step_fn = env.step_stacked if cfg.stacked_obs else env.step   # level5: te_step_stacked (third launch: stacked_kernel)
+        # exp05: one env.step = te_observe_ally -> driver -> te_set_ally_actions -> te_step.  The driver here is synthetic
+        # (pre-generated random actions: the policy network is the caller's, not this library's), the observation is built
+        # every step all the same.
+        external = int(cfg.ally_policy) == 3
+        ally_actions = None
         if external:
-            env.observe_ally()
-            if not pregen:
-                env.random_actions(args.action_seed + 1000, i, out=ally_actions[0])
-            env.set_ally_actions(ally_actions[i if pregen else 0])
-        if pregen:
-            step_fn(actions[i], terminal=True)
-        else:
-            env.random_actions(args.action_seed, i, out=actions[0])
-            step_fn(actions[0], terminal=True)
+            ally_actions = torch.empty((n_total if pregen else 1, n_local, 4), dtype=torch.float32, device=device)
+            if pregen:
+                for i in range(n_total):
+                    env.random_actions(args.action_seed + 1000, i, out=ally_actions[i])
 
-    def armed_per_env() -> float:
-        """Mean number of armed drones per env (disarmed slots are not flown: they cost one flag load)."""
-        from dronechase_amd import config as K
-        w = env.get_state()
-        D = cfg.n_drones
-        return float((w[: n_local * D * K.DRONE_WORDS].view(n_local, D, K.DRONE_WORDS)[:, :, K.D["ARMED"]] != 0).float().sum(1).mean().item())
+        def one_step(i: int):
+            if external:
+                env.observe_ally()
+                if not pregen:
+                    env.random_actions(args.action_seed + 1000, i, out=ally_actions[0])
+                env.set_ally_actions(ally_actions[i if pregen else 0])
+            if pregen:
+                step_fn(actions[i], terminal=True)
+            else:
+                env.random_actions(args.action_seed, i, out=actions[0])
+                step_fn(actions[0], terminal=True)
 
-    n_batches = n_total if pregen else 1
-
-    def timed(first: int, count: int) -> float:
-        """Wall time of `count` consecutive steps starting at rollout step `first`, bracketed by barrier + synchronize on both
-        sides, max over ranks.  Nothing but the step's own launches is enqueued in between (no event records)."""
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for i in range(count):
-            one_step((first + i) % n_batches if pregen else first + i)
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def marker_overhead_ms() -> float:
-        """What a pair of event records adds to whatever sits between them on a busy queue: two records back to back behind a small
-        kernel, median of 64 (5.4 us on an MI355X: the time the command processor takes from one marker to the next).  Subtracted
-        from every bracket of kernel_times()."""
-        scratch = torch.empty((n_local, 4), dtype=torch.float32, device=device)
-        pairs = []
-        for _ in range(64):
-            env.random_actions(1, 0, out=scratch)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); e1.record()
-            pairs.append((e0, e1))
-        torch.cuda.synchronize(device)
-        return float(np.median([a.elapsed_time(b) for a, b in pairs]))
-
-    def kernel_times(first: int, count: int):
-        """Average duration of the two kernels over the `count` steps starting at rollout step `first`, from HIP events on the stream
-        te_step launches on (te_profile_begin/end), minus the markers' own cost.  A SEPARATE loop (regime() replays the window it
-        timed on the wall clock from a saved state): the headline loop must not pay for event records."""
-        env.profile_begin(count)
-        for i in range(count):
-            one_step((first + i) % n_batches if pregen else first + i)
-        torch.cuda.synchronize(device)
-        k1, k2, n = env.profile_end()
-        return max(k1 - ev_over_ms, 0.0), max(k2 - ev_over_ms, 0.0), n, (k1, k2)
-
-    D = cfg.n_drones
-    per_drone = 2 * 176                                           # sub-step kernel: state read + written per armed drone
-    lidar_bytes = (6 if cfg.stacked_obs else 1) * 3 * 338 * 4     # own sphere, or level5's six stacked spheres
-    alg_all = _lib.algorithmic_bytes_per_env_step(cfg)            # SURVEY.md 8(d): every slot armed (8108 B for stage03)
-    alg_k2 = alg_all - (D * per_drone + 16 + lidar_bytes)         # engage/observe kernel (+ stacked_kernel in level5): the rest
-
-    def priced(armed: float):
-        """Algorithmic bytes of one env-step with `armed` drones flown: only ARMED drones are flown (a disarmed slot costs one
-        scalar flag load), so the drone-state term of SURVEY.md 8(d) is priced at the census, not at all D slots."""
-        k1 = armed * per_drone + 16 + lidar_bytes
-        return k1, k1 + alg_k2
-
-    def regime(first: int, count: int, n_events: int, label: str) -> dict:
-        """One measured regime of the rollout: `count` steps on the wall clock (no events), then — unless n_events is 0 — the same
-        `count` steps once more from the saved state with the kernels bracketed by HIP events.  Every fraction of the HBM peak is
-        computed from the WALL time of the step."""
-        a0 = armed_per_env() if rank == 0 else 0.0
-        replay = use_events and n_events > 0
-        saved = env.get_state().clone() if replay else None
-        el = timed(first, count)
-        a1 = armed_per_env() if rank == 0 else 0.0
-        k1_ms = k2_ms = 0.0; n_prof = 0; raw = (0.0, 0.0)
-        if replay:   # the SAME steps again from the saved state (the rollout is deterministic), this time with the kernels bracketed by events
-            env.set_state(saved)
-            k1_ms, k2_ms, n_prof, raw = kernel_times(first, count)
-            del saved
-        armed = 0.5 * (a0 + a1)
-        ms = 1e3 * el / count
-        b_k1, b_step = priced(armed)
-        out = {"label": label, "first_step": first, "steps": count, "value": world * n_local * count / el, "unit": "env-steps/s",
-               "ms_per_step": ms, "armed_drones_per_env": armed, "armed_drones_per_env_begin_end": [a0, a1],
-               "algorithmic_bytes_per_env_step": b_step,
-               "roofline_env_step": {"bound": "hbm", "achieved": b_step * n_local / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": b_step * n_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "from": "wall-clock ms_per_step"}}
-        if n_prof:
-            out["kernels"] = {"substeps_kernel_ms": k1_ms, "engage_observe_kernel_ms": k2_ms, "launches_timed": n_prof,
-                              "timed_in": "a replay of the same steps from the state saved at the start of the window, HIP events on te_step's stream",
-                              "event_brackets_raw_ms": list(raw), "event_pair_overhead_ms": ev_over_ms,
-                              "substeps_kernel_hbm_frac": b_k1 * n_local / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "engage_observe_kernel_hbm_frac": alg_k2 * n_local / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        return out, el, (k1_ms, k2_ms, n_prof, armed)
-
-    use_events = not args.no_profile_events
-    env.reset()
-    ev_over_ms = marker_overhead_ms() if use_events else 0.0
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize(device)
-    # ---- headline: EXACTLY args.steps steps after args.warmup, nothing else in the timed region
-    head, elapsed, (k1_ms, k2_ms, n_prof, armed) = regime(args.warmup, args.steps, args.steps, "headline")
-    done_frac = float(env.done.float().mean().item())
-    extra = {}
-    if not args.headline_only:
-        # ---- steady state: the rollout gets heavier as episodes progress (more invaders per wave, spread over more slots);
-        # fast-forward to step args.steady_after (untimed), then time args.steady_steps steps the same way
-        pos = args.warmup + args.steps   # (the event replay of a window ends where the window ended)
-        for i in range(pos, max(pos, args.steady_after)):
-            one_step(i % n_batches if pregen else i)
-        pos = max(pos, args.steady_after)
-        extra["steady_state"], _, _ = regime(pos, args.steady_steps, 32, f"steady state: steps {pos}..{pos + args.steady_steps} of the same rollout")
-        # ---- every slot armed: the heaviest step the task can ask for (a trained policy in the last waves).  A state blob
-        # with all D drones armed is loaded (te_set_state) and a short window is timed before episodes end and thin it out
-        if int(cfg.task) in (3, 4, 5, 7) and not cfg.stacked_obs and not cfg.evaluation:
+        def armed_per_env() -> float:
+            """Mean number of armed drones per env (disarmed slots are not flown: they cost one flag load)."""
             from dronechase_amd import config as K
-            w = env.get_state().clone()
-            dr = w[: n_local * D * K.DRONE_WORDS].view(n_local, D, K.DRONE_WORDS)
-            er = w[n_local * D * K.DRONE_WORDS: n_local * (D * K.DRONE_WORDS + K.ENV_WORDS)].view(n_local, K.ENV_WORDS)
-            g = torch.Generator(device=device); g.manual_seed(99)
-            # disarmed invaders are put on the born sphere like a new wave would (exp03_vFinal_task.py:584-608), at rest
-            dead = dr[:, :, K.D["ARMED"]] == 0
-            th = torch.rand((n_local, D), device=device, generator=g) * 3.14159265
-            ph = 0.8411 + torch.rand((n_local, D), device=device, generator=g) * (1.5707963 - 0.8411)
-            pos3 = torch.stack((6 * ph.sin() * th.cos(), 6 * ph.sin() * th.sin(), 6 * ph.cos()), -1)
-            fl = dr.view(torch.float32)
-            for k in range(3):
-                fl[:, :, K.D["POS"] + k] = torch.where(dead, pos3[:, :, k], fl[:, :, K.D["POS"] + k])
-                fl[:, :, K.D["OBS_POS"] + k] = torch.where(dead, pos3[:, :, k], fl[:, :, K.D["OBS_POS"] + k])
-            dr[:, :, K.D["ARMED"]] = 1
-            er[:, K.E["ROUND"]] = int(cfg.n_rounds)
-            er[:, K.E["SNAP_MASK"]] = (1 << D) - 1
-            env.set_state(w)
-            extra["all_armed"], _, _ = regime(0, 48, 16, f"every slot armed (round {int(cfg.n_rounds)} state loaded with te_set_state), first 48 steps")
+            w = env.get_state()
+            D = cfg.n_drones
+            return float((w[: n_local * D * K.DRONE_WORDS].view(n_local, D, K.DRONE_WORDS)[:, :, K.D["ARMED"]] != 0).float().sum(1).mean().item())
 
+        n_batches = n_total if pregen else 1
+
+        def timed(first: int, count: int) -> float:
+            """Wall time of `count` consecutive steps starting at rollout step `first`, bracketed by barrier + synchronize on both
+            sides, max over ranks.  Nothing but the step's own launches is enqueued in between (no event records)."""
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(count):
+                one_step((first + i) % n_batches if pregen else first + i)
+            torch.cuda.synchronize(device)
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        def kernel_times(first: int, count: int):
+            """Average duration of the two kernels over the `count` steps starting at rollout step `first`: HIP events on the stream te_step
+            launches on (te_profile_begin/end).  The events are the kernels' own start / stop events (hipExtLaunchKernel: the dispatch's begin /
+            end timestamps, the quantity rocprofv3 --kernel-trace reports), so nothing is subtracted.  A SEPARATE loop (regime() replays the
+            window it timed on the wall clock from a saved state): the headline loop must not pay for event records."""
+            env.profile_begin(count)
+            for i in range(count):
+                one_step((first + i) % n_batches if pregen else first + i)
+            torch.cuda.synchronize(device)
+            return env.profile_end()
+
+        D = cfg.n_drones
+        per_drone = 2 * 176                                           # sub-step kernel: state read + written per armed drone
+        lidar_bytes = (6 if cfg.stacked_obs else 1) * 3 * 338 * 4     # own sphere, or level5's six stacked spheres
+        alg_all = _lib.algorithmic_bytes_per_env_step(cfg)            # SURVEY.md 8(d): every slot armed (8108 B for stage03)
+        alg_k2 = alg_all - (D * per_drone + 16 + lidar_bytes)         # engage/observe kernel (+ stacked_kernel in level5): the rest
+
+        def priced(armed: float):
+            """Algorithmic bytes of one env-step with `armed` drones flown: only ARMED drones are flown (a disarmed slot costs one
+            scalar flag load), so the drone-state term of SURVEY.md 8(d) is priced at the census, not at all D slots."""
+            k1 = armed * per_drone + 16 + lidar_bytes
+            return k1, k1 + alg_k2
+
+        timed_in = ("a replay of the same steps from the state saved at the start of the window; HIP events on te_step's stream = "
+                    + ("marker packets between the launches (TE_PROF=markers: each bracket includes ~5 us of queue time)" if markers else
+                       "the kernels' own start / stop events (hipExtLaunchKernel: dispatch begin / end timestamps, as in rocprofv3 --kernel-trace)"))
+
+        def regime(first: int, count: int, n_events: int, label: str):
+            """One measured regime of the rollout: `count` steps on the wall clock (no events), then — unless n_events is 0 — the same
+            `count` steps once more from the saved state with the kernels timed by HIP events.  Every fraction of the HBM peak is
+            computed from the WALL time of the step."""
+            a0 = armed_per_env() if rank == 0 else 0.0
+            replay = use_events and n_events > 0
+            saved = env.get_state().clone() if replay else None
+            el = timed(first, count)
+            a1 = armed_per_env() if rank == 0 else 0.0
+            k1_ms = k2_ms = 0.0; n_prof = 0
+            if replay:   # the SAME steps again from the saved state (the rollout is deterministic), this time with the kernels timed
+                env.set_state(saved)
+                k1_ms, k2_ms, n_prof = kernel_times(first, count)
+                del saved
+            armed = 0.5 * (a0 + a1)
+            ms = 1e3 * el / count
+            b_k1, b_step = priced(armed)
+            out = {"label": label, "first_step": first, "steps": count, "value": world * n_local * count / el, "unit": "env-steps/s",
+                   "ms_per_step": ms, "armed_drones_per_env": armed, "armed_drones_per_env_begin_end": [a0, a1],
+                   "algorithmic_bytes_per_env_step": b_step,
+                   "roofline_env_step": {"bound": "hbm", "achieved": b_step * n_local / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": b_step * n_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "from": "wall-clock ms_per_step"}}
+            if n_prof:
+                out["kernels"] = {"substeps_kernel_ms": k1_ms, "engage_observe_kernel_ms": k2_ms, "launches_timed": n_prof, "timed_in": timed_in,
+                                  "substeps_kernel_hbm_frac": b_k1 * n_local / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "engage_observe_kernel_hbm_frac": alg_k2 * n_local / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            return out, el, (k1_ms, k2_ms, n_prof, armed)
+
+        env.reset()
+        for i in range(args.warmup):
+            one_step(i)
+        torch.cuda.synchronize(device)
+        # ---- headline: EXACTLY args.steps steps after args.warmup, nothing else in the timed region
+        head, elapsed, (k1_ms, k2_ms, n_prof, armed) = regime(args.warmup, args.steps, args.steps, "headline")
+        done_frac = float(env.done.float().mean().item())
+        extra = {}
+        if not headline_only:
+            # ---- steady state: the rollout gets heavier as episodes progress (more invaders per wave, spread over more slots);
+            # fast-forward to step args.steady_after (untimed), then time args.steady_steps steps the same way
+            pos = args.warmup + args.steps   # (the event replay of a window ends where the window ended)
+            for i in range(pos, max(pos, args.steady_after)):
+                one_step(i % n_batches if pregen else i)
+            pos = max(pos, args.steady_after)
+            extra["steady_state"], _, _ = regime(pos, args.steady_steps, 32, f"steady state: steps {pos}..{pos + args.steady_steps} of the same rollout")
+            # ---- every slot armed: the heaviest step the task can ask for (a trained policy in the last waves).  A state blob
+            # with all D drones armed is loaded (te_set_state) and a short window is timed before episodes end and thin it out
+            if int(cfg.task) in (3, 4, 5, 7) and not cfg.stacked_obs and not cfg.evaluation:
+                from dronechase_amd import config as K
+                w = env.get_state().clone()
+                dr = w[: n_local * D * K.DRONE_WORDS].view(n_local, D, K.DRONE_WORDS)
+                er = w[n_local * D * K.DRONE_WORDS: n_local * (D * K.DRONE_WORDS + K.ENV_WORDS)].view(n_local, K.ENV_WORDS)
+                g = torch.Generator(device=device); g.manual_seed(99)
+                # disarmed invaders are put on the born sphere like a new wave would (exp03_vFinal_task.py:584-608), at rest
+                dead = dr[:, :, K.D["ARMED"]] == 0
+                th = torch.rand((n_local, D), device=device, generator=g) * 3.14159265
+                ph = 0.8411 + torch.rand((n_local, D), device=device, generator=g) * (1.5707963 - 0.8411)
+                pos3 = torch.stack((6 * ph.sin() * th.cos(), 6 * ph.sin() * th.sin(), 6 * ph.cos()), -1)
+                fl = dr.view(torch.float32)
+                for k in range(3):
+                    fl[:, :, K.D["POS"] + k] = torch.where(dead, pos3[:, :, k], fl[:, :, K.D["POS"] + k])
+                    fl[:, :, K.D["OBS_POS"] + k] = torch.where(dead, pos3[:, :, k], fl[:, :, K.D["OBS_POS"] + k])
+                dr[:, :, K.D["ARMED"]] = 1
+                er[:, K.E["ROUND"]] = int(cfg.n_rounds)
+                er[:, K.E["SNAP_MASK"]] = (1 << D) - 1
+                env.set_state(w)
+                extra["all_armed"], _, _ = regime(0, 48, 16, f"every slot armed (round {int(cfg.n_rounds)} state loaded with te_set_state), first 48 steps")
+
+        out = {}
+        if rank == 0:
+            value = world * n_local * args.steps / elapsed
+            b_k1, alg = priced(armed)
+            out = {
+                "metric": "env-steps/sec (whole job), random-action rollout",
+                "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{args.task} (level4 exp03-vFinal shape: {cfg.n_pursuers} pursuers + {cfg.n_invaders} "
+                                       f"invader slots, of which {armed:.1f} drones per env are armed (flown) in the timed window; "
+                                       f"{'stacked-sphere LIDAR 6x3x13x26' if cfg.stacked_obs else 'own-sphere LIDAR 3x13x26'}), {world * n_local} envs in total = {n_local} envs per GPU, "
+                                       f"16 physics sub-steps per env-step, random actions, motor noise {'on' if cfg.motor_noise else 'off'}, auto-reset on",
+                           "task": args.task, "envs_per_gpu": n_local, "total_envs": world * n_local, "drone_slots_per_env": D,
+                           "armed_drones_per_env": armed, "parallelism": f"env-sharded x{world}, no collective"},
+                "done_fraction_last_step": done_frac,
+            }
+            if n_prof:
+                dom_ms, dom_name, dom_bytes = max((k1_ms, "substeps_kernel", b_k1), (k2_ms, "engage_observe_kernel", alg_k2))
+                ach = dom_bytes * n_local / (dom_ms * 1e-3) / 1e9
+                traffic, traffic_source = None, None
+                pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+                if os.path.exists(pmc) and args.task in ("stage03", "exp03") and n_local == 65536 and not args.n_invaders:  # what the PMC passes were taken on
+                    try:
+                        rec = json.load(open(pmc))
+                        traffic = rec.get(dom_name, {}).get("hbm_bytes_per_launch")
+                        traffic_source = f"profiles/pmc_latest.json ({rec.get('source', 'separate rocprofv3 --pmc passes of this command')}): not measured in this run"
+                    except Exception:
+                        traffic = None
+                out["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                                   "algorithmic_bytes_per_launch": dom_bytes * n_local, "avg_launch_ms": dom_ms,
+                                   "launches_timed": n_prof, "timed_in": timed_in,
+                                   "armed_drones_per_env": armed,
+                                   "valu_issue_frac_substeps_kernel": (armed * n_local / 64.0) * SUBSTEPS * VALU_CLOCKS_PER_DRONE_SUBSTEP
+                                                                      / (SIMDS * CLOCK_HZ * k1_ms * 1e-3),
+                                   "armed_drones_per_env_begin_end": head["armed_drones_per_env_begin_end"]}
+            step_ms = 1e3 * elapsed / args.steps
+            out["roofline_env_step"] = {"bound": "hbm", "achieved": alg * n_local / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": alg * n_local / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "from": "wall-clock ms_per_step of the headline window (per GPU)",
+                                        "algorithmic_bytes_per_env_step": alg, "algorithmic_bytes_all_armed": alg_all, "substeps_kernel_ms": k1_ms,
+                                        "engage_observe_kernel_ms": k2_ms}
+            out.update(extra)
+        env.close()
+        del env, actions
+        torch.cuda.empty_cache()
+        return out
+
+    if args.envs_per_gpu:       # an explicit shard size: per-GPU work fixed as N grows
+        out = measure(args.envs_per_gpu, args.headline_only, "weak")
+    else:                       # BASELINE.json's configuration: --total-envs in total, split over the ranks
+        if args.total_envs % world:
+            raise SystemExit(f"--total-envs {args.total_envs} does not split over {world} ranks")
+        out = measure(args.total_envs // world, args.headline_only, "weak" if world == 1 else "strong")
+        if world > 1 and not args.no_weak_block:
+            # the size one MI355X is efficient at, on every rank: what the node delivers when the caller has 65 536 envs PER GPU
+            wk = measure(args.total_envs, True, "weak")
+            if rank == 0:
+                out["weak_scaling"] = {k: wk[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "roofline", "roofline_env_step") if k in wk}
     if rank == 0:
-        value = world * n_local * args.steps / elapsed
-        b_k1, alg = priced(armed)
-        out = {
-            "metric": "env-steps/sec (whole job), random-action rollout",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.task} (level4 exp03-vFinal shape: {cfg.n_pursuers} pursuers + {cfg.n_invaders} "
-                                   f"invader slots, of which {armed:.1f} drones per env are armed (flown) in the timed window; "
-                                   f"{'stacked-sphere LIDAR 6x3x13x26' if cfg.stacked_obs else 'own-sphere LIDAR 3x13x26'}), {n_local} envs per GPU, 16 physics sub-steps per env-step, "
-                                   f"random actions, motor noise {'on' if cfg.motor_noise else 'off'}, auto-reset on",
-                       "task": args.task, "envs_per_gpu": n_local, "total_envs": world * n_local, "drone_slots_per_env": D,
-                       "armed_drones_per_env": armed, "parallelism": f"env-sharded x{world}, no collective"},
-            "done_fraction_last_step": done_frac,
-        }
-        if n_prof:
-            dom_ms, dom_name, dom_bytes = max((k1_ms, "substeps_kernel", b_k1), (k2_ms, "engage_observe_kernel", alg_k2))
-            ach = dom_bytes * n_local / (dom_ms * 1e-3) / 1e9
-            traffic, traffic_source = None, None
-            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc) and args.task in ("stage03", "exp03") and n_local == 65536 and not args.n_invaders:  # what the PMC passes were taken on
-                try:
-                    rec = json.load(open(pmc))
-                    traffic = rec.get(dom_name, {}).get("hbm_bytes_per_launch")
-                    traffic_source = f"profiles/pmc_latest.json ({rec.get('source', 'separate rocprofv3 --pmc passes of this command')}): not measured in this run"
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                               "algorithmic_bytes_per_launch": dom_bytes * n_local, "avg_launch_ms": dom_ms,
-                               "launches_timed": n_prof,
-                               "timed_in": "a replay of the headline window from the state saved at its start: the same steps, HIP events on te_step's stream, "
-                                           "minus event_pair_overhead_ms per bracket (two event records back to back on a busy queue, measured in this run)",
-                               "event_pair_overhead_ms": ev_over_ms, "event_bracket_raw_ms": head["kernels"]["event_brackets_raw_ms"][0 if dom_name == "substeps_kernel" else 1],
-                               "armed_drones_per_env": armed,
-                               "valu_issue_frac_substeps_kernel": (armed * n_local / 64.0) * SUBSTEPS * VALU_CLOCKS_PER_DRONE_SUBSTEP
-                                                                  / (SIMDS * CLOCK_HZ * k1_ms * 1e-3),
-                               "armed_drones_per_env_begin_end": head["armed_drones_per_env_begin_end"]}
-        step_ms = 1e3 * elapsed / args.steps
-        out["roofline_env_step"] = {"bound": "hbm", "achieved": alg * n_local / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": alg * n_local / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "from": "wall-clock ms_per_step of the headline window",
-                                    "algorithmic_bytes_per_env_step": alg, "algorithmic_bytes_all_armed": alg_all, "substeps_kernel_ms": k1_ms,
-                                    "engage_observe_kernel_ms": k2_ms}
-        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.task, overrides, args.action_seed, args.cpu_seconds)
             except Exception as exc:  # the baseline is a reported extra: never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
         print(json.dumps(out), flush=True)
-    env.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -43,22 +43,25 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
     tag = f".{os.getpid()}"  # unique temporaries: two processes building at once each write their own files and the last
     # os.replace wins with a complete library (never a half-written one)
     obj = os.path.join(CSRC, f"te_config{tag}.o")
-    subprocess.run(["gcc", "-O2", "-fPIC", "-fvisibility=hidden", "-c", os.path.join(CSRC, "te_config.c"), "-o", obj],
-                   check=True)
     hobj = os.path.join(CSRC, f"te_env{tag}.o")
+    tmp = LIB + tag + ".tmp"
     # -fno-slp-vectorize: the SLP vectorizer turns the scalar fp32 physics into v_pk_* pairs; on gfx950 that saves
     # no instructions here (the pairs cost as many v_mov to assemble) but needs 95 instead of 72 VGPRs in the
     # sub-step kernel, i.e. 5 instead of 7 waves per SIMD
-    compile_cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-gpu-rdc",
-                   "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", *extra_flags, "-c", os.path.join(CSRC, "te_env.hip"), "-o", hobj]
-    link_cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", hobj, obj, "-o", LIB + tag + ".tmp", "-lm"]
-    for cmd in (compile_cmd, link_cmd):
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True)
-    os.remove(hobj)
-    os.replace(LIB + tag + ".tmp", LIB)
-    os.remove(obj)
+    cmds = [["gcc", "-O2", "-fPIC", "-fvisibility=hidden", "-c", os.path.join(CSRC, "te_config.c"), "-o", obj],
+            [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-gpu-rdc",
+             "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", *extra_flags, "-c", os.path.join(CSRC, "te_env.hip"), "-o", hobj],
+            [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", hobj, obj, "-o", tmp, "-lm"]]
+    try:
+        for cmd in cmds:
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB)
+    finally:   # an interrupted or failed build leaves nothing behind (stale objects would travel to the GPU box)
+        for f in (obj, hobj, tmp):
+            if os.path.exists(f):
+                os.remove(f)
     return LIB
 
 

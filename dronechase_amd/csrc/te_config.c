@@ -32,9 +32,10 @@ static int calculate_max_rounds(int pursuers, int munition, int initial_invaders
   return (int)ceil((-b + sqrt(b * b + 8.0 * total)) / 2.0);
 }
 
-/* PyFlyt 0.11.1 "cf2x" (models/vehicles/cf2x/cf2x.yaml + cf2x.urdf), recorded in SURVEY.md
- * Appendix B from the public sources.  UNVERIFIED here: pyflyt is absent from this container. */
-static void cf2x_defaults(te_quad_params* q) {
+/* PyFlyt 0.11.1 "cf2x" (models/vehicles/cf2x/cf2x.yaml + cf2x.urdf) as recalled in SURVEY.md Appendix B from the public
+ * sources.  UNVERIFIED: pyflyt is absent from this container, and this table FAILS the one PyBullet recording the reference
+ * holds (chi^2 / dof 5.3, tools/physics_fit.py): selectable as TE_QUAD_CF2X_RECALLED, no longer the default (round 3). */
+static void cf2x_recalled(te_quad_params* q) {
   q->mass = 0.027f;
   q->inertia[0] = 1.4e-5f; q->inertia[1] = 1.4e-5f; q->inertia[2] = 2.17e-5f;
   q->arm = 0.028f;
@@ -60,10 +61,12 @@ static void cf2x_defaults(te_quad_params* q) {
   q->pwm_floor = 0.05f;
 }
 
-/* The recalled table with the smallest change that reproduces the recorded PyBullet observations (io_data0.h5) within their
- * motor-noise scatter: tools/physics_fit.py, DESIGN.md 5.  Filled in by that study; NOT a default of any task. */
+/* THE DEFAULT OF EVERY TASK (round 3): the recalled table with the fewest changed entries that reproduce the recorded PyBullet
+ * observations (src/core/rl_framework/utils/output/collect_and_save/io_data0.h5) within their motor-noise scatter under the
+ * reference's loop as it reads (update_control on every 240 Hz sub-step, level4_simulation.py:92-94): tools/physics_fit.py,
+ * DESIGN.md 5, profiles/r03_physics_fit_headline.md.  A fit to 147 numbers, not a verified table: PyBullet parity stays unpinned. */
 static void cf2x_recorded_fit(te_quad_params* q) {
-  cf2x_defaults(q);
+  cf2x_recalled(q);
   /* tools/physics_fit.py: chi^2 / dof 5.3 -> 0.29 against the 147 recorded numbers with these two entries:
    * the roll / pitch rate loop answers ~6x faster than the recalled table makes it (its product kp * arm * thrust / inertia
    * is what the data identifies: the gain is the entry changed here), and the motors follow their command within one
@@ -74,7 +77,7 @@ static void cf2x_recorded_fit(te_quad_params* q) {
 
 TE_API int te_quad_preset(te_config* c, int32_t preset) {
   if (!c) return 1;
-  if (preset == TE_QUAD_CF2X_RECALLED) cf2x_defaults(&c->quad);
+  if (preset == TE_QUAD_CF2X_RECALLED) cf2x_recalled(&c->quad);
   else if (preset == TE_QUAD_CF2X_RECORDED_FIT) cf2x_recorded_fit(&c->quad);
   else return 2;
   c->quad_preset = preset;
@@ -88,7 +91,7 @@ TE_API int te_config_default(te_config* c, int32_t task) {
   c->task = task;
   c->control_every_substep = 1; /* level4_simulation.py:92-94: update_control inside the 240 Hz loop */
   c->lidar_channels = TE_LIDAR_CHANNELS; c->io_location = TE_IO_DEVICE;
-  c->drone_contact = 0; c->contact_radius = 0.06f; c->quad_preset = TE_QUAD_CF2X_RECALLED;
+  c->drone_contact = 0; c->contact_radius = 0.06f; c->quad_preset = TE_QUAD_CF2X_RECORDED_FIT;
   c->initial_invaders = 1; c->invaders_per_round = 1; c->agent_scripted = 0; c->reward_model = TE_REWARD_EXP03; c->agent_death_terminates = 1;
   c->ground_contact = 0; c->ground_z = -6.0f; c->hull_half_height = 0.0125f; /* plane.urdf at z = -6 (entities_manager.py:120-124): opt-in */
   c->n_envs = 1;
@@ -107,7 +110,7 @@ TE_API int te_config_default(te_config* c, int32_t task) {
   c->motor_noise = 1;
   c->auto_reset = 1;
   c->catch_distance = 0.4f;
-  cf2x_defaults(&c->quad);
+  cf2x_recorded_fit(&c->quad);
   switch (task) {
     case TE_TASK_STAGE01: /* level2/pyflyt_level2_environment_modified_v2.py:27-73 */
       c->n_pursuers = 2; c->n_invaders = 1;

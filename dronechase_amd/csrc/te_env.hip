@@ -20,12 +20,14 @@
 //
 // Reference citations are file:line under the reference's src/ tree.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -834,6 +836,7 @@ struct te_env {
   // profiling (te_profile_begin / te_profile_end)
   std::vector<hipEvent_t> events;
   int prof_cap = 0, prof_used = 0;
+  bool prof_markers = false;   // TE_PROF=markers: marker packets between the launches instead of the kernels' own start / stop events
 };
 
 static thread_local std::string g_err;
@@ -885,6 +888,17 @@ __global__ __launch_bounds__(64) void gather_rows_kernel(const float* __restrict
 static bool host_io(const te_env* e) { return e && e->p.cfg.io_location == TE_IO_HOST; }
 #define TE_H2D(dst, src, bytes) do { if ((src) && (bytes)) TE_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
 #define TE_D2H(dst, src, bytes) do { if ((dst) && (bytes)) TE_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, st)); } while (0)
+
+// A launch whose start / stop events carry the dispatch's own begin / end timestamps (hipExtLaunchKernel); the arguments are converted to the
+// kernel's formal types first, as a <<<>>> launch would
+template <typename... Formals, typename... Actuals>
+static void launch_timed(void (*kernel)(Formals...), dim3 grid, dim3 block, unsigned lds, hipStream_t st, hipEvent_t start, hipEvent_t stop, Actuals&&... actuals) {
+  static_assert(sizeof...(Formals) == sizeof...(Actuals), "argument count");
+  std::tuple<Formals...> held{std::forward<Actuals>(actuals)...};
+  void* ptrs[sizeof...(Formals)];
+  std::apply([&](auto&... a) { int i = 0; ((ptrs[i++] = (void*)&a), ...); }, held);
+  (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, st, start, stop, 0);
+}
 
 extern "C" {
 
@@ -1199,8 +1213,18 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   DeviceGuard guard(e->device);
   hipStream_t st = (hipStream_t)stream;
   const Params& p = e->p;
-  const bool prof = e->prof_used + 3 <= e->prof_cap;
-  if (prof) TE_HIP(hipEventRecord(e->events[e->prof_used + 0], st));
+  // Profiling (te_profile_begin): 4 events per step.  Default: the kernels are launched with hipExtLaunchKernel, whose start / stop events
+  // carry the dispatch's own begin / end timestamps (what rocprofv3 --kernel-trace reports): [0, 1] = the sub-step kernel, [2] = start of the
+  // engage kernel, [3] = end of the step's last kernel.  TE_PROF=markers: round-2 form, marker packets between the launches (each bracket
+  // then includes ~5 us of queue time: tools/event_overhead_probe.py).
+  const bool prof = e->prof_used + 4 <= e->prof_cap;
+  const bool prof_ext = prof && !e->prof_markers;
+  hipEvent_t* pev = prof ? &e->events[e->prof_used] : nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;   // start / stop events of the next TE_LAUNCH
+#define TE_LAUNCH(K, grid, block, lds, ...) do { \
+    if (ev_a || ev_b) launch_timed(K, grid, block, lds, st, ev_a, ev_b, __VA_ARGS__); \
+    else hipLaunchKernelGGL(K, grid, block, lds, st, __VA_ARGS__); } while (0)
+  if (prof && !prof_ext) TE_HIP(hipEventRecord(pev[0], st));
   const int waves = p.D * (p.Npad >> 6);
   const bool noise = p.cfg.motor_noise != 0;
   // LIDAR background: N*1014 floats = quads float4 (+ <4 tail floats).  The drone waves write one float4 per
@@ -1216,57 +1240,63 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
       hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, obs_lidar, n_floats);
     }
   }
+  if (prof_ext) { ev_a = pev[0]; ev_b = pev[1]; }
   const int b1 = (int)fill.n_fill_waves + waves + (e->family == FAM_LEVEL4 && p.dense_min > 1 ? kMixedWaves * (p.Npad >> 6) : 0);  // + mixed-wave candidates
   launch_by_family(e->family, [&](auto fam) {
     constexpr int F = decltype(fam)::value;
     auto go = [&](auto noise_c, auto fill_c) {
       if (p.cfg.control_every_substep)
-        hipLaunchKernelGGL((substeps_kernel<F, decltype(noise_c)::value, decltype(fill_c)::value, true>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p, actions, fill);
+        TE_LAUNCH((substeps_kernel<F, decltype(noise_c)::value, decltype(fill_c)::value, true>), dim3(b1), dim3(TE_K1_BLOCK), 0, p, actions, fill);
       else
-        hipLaunchKernelGGL((substeps_kernel<F, decltype(noise_c)::value, decltype(fill_c)::value, false>), dim3(b1), dim3(TE_K1_BLOCK), 0, st, p, actions, fill);
+        TE_LAUNCH((substeps_kernel<F, decltype(noise_c)::value, decltype(fill_c)::value, false>), dim3(b1), dim3(TE_K1_BLOCK), 0, p, actions, fill);
     };
     if (noise) { if (fill.lidar) go(std::true_type{}, std::true_type{}); else go(std::true_type{}, std::false_type{}); }
     else { if (fill.lidar) go(std::false_type{}, std::true_type{}); else go(std::false_type{}, std::false_type{}); }
   });
-  if (prof) TE_HIP(hipEventRecord(e->events[e->prof_used + 1], st));
+  if (prof && !prof_ext) { TE_HIP(hipEventRecord(pev[1], st)); TE_HIP(hipEventRecord(pev[2], st)); }
+  if (prof_ext) { ev_a = pev[2]; ev_b = stack ? nullptr : pev[3]; }
   const int b2 = (p.N + kEPB - 1) / kEPB;
   // the engage/observe kernel patches the agent's own sphere only in the classic layout; in stacked mode all LIDAR
   // output comes from stacked_kernel
   StepOut o{reward, done, info, ObsOut{stack ? nullptr : obs_lidar, obs_inertial, obs_last_action},
             ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}};
   const bool contact = p.cfg.drone_contact != 0;   // its own instantiations: the contact pass would cost every launch ~150 VGPRs
-  if (e->engage_regs == 1 && !contact) hipLaunchKernelGGL((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, st, p, actions, o);
-  else if (e->engage_regs == 2 && !contact) hipLaunchKernelGGL((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  if (e->engage_regs == 1 && !contact) TE_LAUNCH((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, p, actions, o);
+  else if (e->engage_regs == 2 && !contact) TE_LAUNCH((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, p, actions, o);
 #ifndef TE_DEBUG_STAMPS  // the stamp build leaves the contact variants out (the compiler rejects them next to the stamp stores)
-  else if (e->engage_regs == 1) hipLaunchKernelGGL((engage_kernel<2, 9, true>), dim3(b2), dim3(64), 0, st, p, actions, o);
-  else if (e->engage_regs == 2) hipLaunchKernelGGL((engage_kernel<6, 12, true>), dim3(b2), dim3(64), 0, st, p, actions, o);
+  else if (e->engage_regs == 1) TE_LAUNCH((engage_kernel<2, 9, true>), dim3(b2), dim3(64), 0, p, actions, o);
+  else if (e->engage_regs == 2) TE_LAUNCH((engage_kernel<6, 12, true>), dim3(b2), dim3(64), 0, p, actions, o);
 #endif
-  else if (e->engage_regs == 5) hipLaunchKernelGGL((engage_kernel<7, 30>), dim3(b2), dim3(64), 0, st, p, actions, o);
-  else if (e->engage_regs == 3) hipLaunchKernelGGL((engage_stage02_kernel<2, 8>), dim3(b2), dim3(64), 0, st, p, actions, o);
-  else if (e->engage_regs == 4) hipLaunchKernelGGL(engage_stage01_kernel, dim3(b2), dim3(64), 0, st, p, actions, o);
+  else if (e->engage_regs == 5) TE_LAUNCH((engage_kernel<7, 30>), dim3(b2), dim3(64), 0, p, actions, o);
+  else if (e->engage_regs == 3) TE_LAUNCH((engage_stage02_kernel<2, 8>), dim3(b2), dim3(64), 0, p, actions, o);
+  else if (e->engage_regs == 4) TE_LAUNCH(engage_stage01_kernel, dim3(b2), dim3(64), 0, p, actions, o);
   else launch_by_family(e->family, [&](auto fam) {
-    if (e->k2_threads == 512) hipLaunchKernelGGL((engage_observe_kernel<FAM_LEVEL4, 512>), dim3(b2), dim3(512), e->lds_bytes, st, p, actions, o);
-    else hipLaunchKernelGGL((engage_observe_kernel<decltype(fam)::value>), dim3(b2), dim3(256), e->lds_bytes, st, p, actions, o);
+    if (e->k2_threads == 512) TE_LAUNCH((engage_observe_kernel<FAM_LEVEL4, 512>), dim3(b2), dim3(512), e->lds_bytes, p, actions, o);
+    else TE_LAUNCH((engage_observe_kernel<decltype(fam)::value>), dim3(b2), dim3(256), e->lds_bytes, p, actions, o);
   });
   if (stack) {
+    ev_a = nullptr; ev_b = nullptr;
     // the first launch pushes this step's ring entries (all wingmen) and serves observer 0; te_step_students adds one launch per further wingman
     if (e->stack_regs) {  // one wave per (chunk, wingman) pushes this step's ring entries, then one 5-wave workgroup per chunk and observer
       StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 1, 0, n_obs};
       const unsigned push_waves = (unsigned)b2 * (unsigned)p.cfg.n_pursuers;
-      if (e->stack_regs == 18) hipLaunchKernelGGL((ring_push_kernel<18>), dim3(push_waves), dim3(64), 0, st, sp);
-      else hipLaunchKernelGGL((ring_push_kernel<37>), dim3(push_waves), dim3(64), 0, st, sp);
+      if (e->stack_regs == 18) TE_LAUNCH((ring_push_kernel<18>), dim3(push_waves), dim3(64), 0, sp);
+      else TE_LAUNCH((ring_push_kernel<37>), dim3(push_waves), dim3(64), 0, sp);
       for (int ob = 0; ob < n_obs; ++ob) {
         sp.push = ob == 0 ? 1 : 0; sp.observer = ob;   // the first view clears the ring of auto-reset envs when it is through
-        if (e->stack_regs == 18) hipLaunchKernelGGL((stack_view_kernel<18>), dim3(b2), dim3(kViewThreads), e->view_lds_bytes, st, sp, *stack);
-        else hipLaunchKernelGGL((stack_view_kernel<37>), dim3(b2), dim3(kViewThreads), e->view_lds_bytes, st, sp, *stack);
+        if (prof_ext && ob == n_obs - 1) ev_b = pev[3];
+        if (e->stack_regs == 18) TE_LAUNCH((stack_view_kernel<18>), dim3(b2), dim3(kViewThreads), e->view_lds_bytes, sp, *stack);
+        else TE_LAUNCH((stack_view_kernel<37>), dim3(b2), dim3(kViewThreads), e->view_lds_bytes, sp, *stack);
       }
     } else
     for (int ob = 0; ob < n_obs; ++ob) {
       StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, ob == 0 ? 1 : 0, ob, n_obs};
-      hipLaunchKernelGGL(stacked_kernel, dim3(b2), dim3(kStackThreads), e->stack_lds_bytes, st, sp, *stack);
+      if (prof_ext && ob == n_obs - 1) ev_b = pev[3];
+      TE_LAUNCH(stacked_kernel, dim3(b2), dim3(kStackThreads), e->stack_lds_bytes, sp, *stack);
     }
   }
-  if (prof) { TE_HIP(hipEventRecord(e->events[e->prof_used + 2], st)); e->prof_used += 3; }
+#undef TE_LAUNCH
+  if (prof) { if (!prof_ext) TE_HIP(hipEventRecord(pev[3], st)); e->prof_used += 4; }
   TE_HIP(hipGetLastError());
   return 0;
 }
@@ -1486,12 +1516,14 @@ __attribute__((visibility("default"))) int te_set_state(te_env* e, const void* s
 __attribute__((visibility("default"))) int te_profile_begin(te_env* e, int32_t max_steps) {
   if (!e || max_steps < 1) return fail("te_profile_begin: bad argument");
   DeviceGuard guard(e->device);
-  while ((int)e->events.size() < 3 * max_steps) {
+  while ((int)e->events.size() < 4 * max_steps) {
     hipEvent_t ev;
     TE_HIP(hipEventCreate(&ev));
     e->events.push_back(ev);
   }
-  e->prof_cap = 3 * max_steps;
+  const char* mode = getenv("TE_PROF");
+  e->prof_markers = mode && !strcmp(mode, "markers");
+  e->prof_cap = 4 * max_steps;
   e->prof_used = 0;
   return 0;
 }
@@ -1499,13 +1531,13 @@ __attribute__((visibility("default"))) int te_profile_begin(te_env* e, int32_t m
 __attribute__((visibility("default"))) int te_profile_end(te_env* e, float* substeps_ms, float* engage_observe_ms, int32_t* n_steps) {
   if (!e) return fail("te_profile_end: null env");
   DeviceGuard guard(e->device);
-  const int n = e->prof_used / 3;
+  const int n = e->prof_used / 4;
   double a = 0, b = 0;
   if (n > 0) TE_HIP(hipEventSynchronize(e->events[e->prof_used - 1]));
   for (int i = 0; i < n; ++i) {
     float m1 = 0, m2 = 0;
-    TE_HIP(hipEventElapsedTime(&m1, e->events[3 * i], e->events[3 * i + 1]));
-    TE_HIP(hipEventElapsedTime(&m2, e->events[3 * i + 1], e->events[3 * i + 2]));
+    TE_HIP(hipEventElapsedTime(&m1, e->events[4 * i], e->events[4 * i + 1]));
+    TE_HIP(hipEventElapsedTime(&m2, e->events[4 * i + 2], e->events[4 * i + 3]));
     a += m1; b += m2;
   }
   if (substeps_ms) *substeps_ms = n ? (float)(a / n) : 0.0f;

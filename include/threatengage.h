@@ -388,10 +388,13 @@ int te_set_state(te_env* env, const void* src_device, size_t words, void* stream
 /* Algorithmic HBM bytes one te_step moves per environment (SURVEY.md 8(d) formula). */
 int te_algorithmic_bytes_per_env_step(const te_config* cfg, size_t* out_bytes);
 
-/* Kernel timing with HIP events recorded on the stream te_step launches on.  After te_profile_begin
- * the next `max_steps` te_step calls bracket each of their two kernels with events; te_profile_end
- * blocks until they have finished and returns the average duration of the sub-step kernel and of the
- * engage/observe kernel in milliseconds, and how many steps were recorded. */
+/* Kernel timing with HIP events on the stream te_step launches on.  After te_profile_begin the next
+ * `max_steps` te_step calls launch their kernels with start / stop events (hipExtLaunchKernelGGL: the
+ * dispatch's own begin / end timestamps, the quantity rocprofv3 --kernel-trace reports; TE_PROF=markers
+ * in the environment selects marker packets between the launches instead); te_profile_end blocks until
+ * they have finished and returns the average duration of the sub-step kernel and of the rest of the
+ * step (engage kernel start to the end of the step's last kernel) in milliseconds, and how many steps
+ * were recorded. */
 int te_profile_begin(te_env* env, int32_t max_steps);
 int te_profile_end(te_env* env, float* substeps_ms, float* engage_observe_ms, int32_t* n_steps);
 

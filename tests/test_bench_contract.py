@@ -27,6 +27,8 @@ def test_bench_line_has_the_contract_keys():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["avg_launch_ms"] > 0 and "traffic" in r
+    # the fraction follows from the kernel's own start / stop events (no marker correction): algorithmic bytes / avg launch / 8 TB/s
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"] and "hipExtLaunchKernel" in r["timed_in"]
     # every regime prices its HBM fraction from its own wall-clock ms_per_step
     e = d["roofline_env_step"]
     assert abs(e["frac"] - e["algorithmic_bytes_per_env_step"] * 4096 / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9

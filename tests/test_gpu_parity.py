@@ -19,8 +19,9 @@ STATE_TOL = 1e-4
 OBS_TOL = 1e-5
 MARGIN = 1e-4
 TASKS = [("exp03", {}), ("exp02", {}), ("exp04", {}), ("exp05", {}), ("stage02", {}), ("stage02", {"n_invaders": 8}), ("stage01", {}),
-         # SURVEY.md A.7 switches: PyFlyt-native 120 Hz controller (control_every_substep = 0), the recorded-fit quadrotor table
-         ("exp03", {"control_every_substep": 0}), ("stage01", {"control_every_substep": 0}), ("exp03", {"quad_preset": 1}),
+         # SURVEY.md A.7 switches: PyFlyt-native 120 Hz controller (control_every_substep = 0), the recalled quadrotor table (the default of
+         # every task is the recorded-fit table since round 3)
+         ("exp03", {"control_every_substep": 0}), ("stage01", {"control_every_substep": 0}), ("exp03", {"quad_preset": 0}),
          ("exp03", {"lidar_channels": 2}), ("stage02", {"lidar_channels": 2})]
 
 

@@ -23,13 +23,13 @@ def test_presets_leave_the_ground_off():
 
 
 def _dive(ground):
-    """A wingman 0.29 m above the plane falling at 3 m/s (more than its motors can arrest in that distance), its target
+    """A wingman 0.29 m above the plane falling at 4 m/s (more than its motors can arrest in that distance), its target
     level with it and far away: z of the hull centre over the next 12 env-steps."""
     cfg, env = _env(ground_contact=ground)
     rest = cfg.ground_z + cfg.hull_half_height
     arena(cfg, env, agent=(0, 0, rest + 0.29), invaders=((9.0, 0, rest + 0.29),))
     b = load(env, cfg)
-    b.set_f(0, 0, "VEL", [0.0, 0.0, -3.0])
+    b.set_f(0, 0, "VEL", [0.0, 0.0, -4.0])
     env.set_state(b.w)
     zs = []
     for _ in range(12):
@@ -40,7 +40,7 @@ def _dive(ground):
 
 def test_a_drone_flown_into_the_ground_stops_on_it_and_can_take_off_again():
     cfg, env, rest, zs = _dive(1)
-    assert rest - 1e-6 <= zs.min() < rest + 5e-3      # it reached the plane (sampled at env-step boundaries) and never went below
+    assert rest - 1e-6 <= zs.min() < rest + 2e-2      # it reached the plane (sampled at env-step boundaries: it may have left it again by up to 16 sub-steps of climb) and never went below
     _, _, _, zs0 = _dive(0)
     assert zs0.min() < rest - 0.02                                       # without the plane the same dive goes through z = rest
     # the contact is one-sided: with its target 3 m up the wingman leaves the ground again

@@ -73,9 +73,14 @@ def simulate(cfg, w, hidden3, noise_env=-1):
     return O.fly_hidden(cfg, 6, [SP[w], SP[w + W]], [0, 16], 32, [0, 0, 0], h, noise_env)
 
 
-def make_cfg(mult=None, control_every_substep=1, control_dt=None, preset=0):
+def make_cfg(mult=None, control_every_substep=1, control_dt=None, preset=0, assign=None):
+    """mult: entry -> factor on the RECALLED table (preset 0 = TE_QUAD_CF2X_RECALLED, whatever te_config_default picks); assign: entry -> values."""
     cfg = O.default_config("level5", n_envs=1, quad_preset=preset)
     q = cfg.quad
+    for name, vals in (assign or {}).items():
+        arr = getattr(q, name)
+        for i, v in enumerate(vals):
+            arr[i] = v
     for name, m in (mult or {}).items():
         if name == "inertia_xy": q.inertia[0] *= m; q.inertia[1] *= m
         elif name == "ang_vel_kp_xy": q.ang_vel_kp[0] *= m; q.ang_vel_kp[1] *= m
@@ -138,6 +143,7 @@ def ratios(sims):
 
 
 DOF = W * 21 - W * 3
+LATER = {"ang_vel_kp": (4.0e-2, 4.0e-2, 8.0e-2), "ang_vel_ki": (5.0e-7, 5.0e-7, 2.7e-4)}
 
 
 def row(label, cfg, sigma, own=False):
@@ -183,6 +189,12 @@ def main():
                        ("update_control at 120 Hz (control_every_substep = 0)", make_cfg(control_every_substep=0)),
                        ("PID period 1/240 (control_dt = physics_dt)", make_cfg(control_dt=1 / 240)),
                        ("recorded-fit preset (te_quad_preset 1: ang_vel_kp_xy x 6, motor_tau x 0.4)", make_cfg(preset=1)),
+                       # round 3: a later published cf2x rate-loop table as recollected by the round-2 review (unverified): ang_vel kp / ki only
+                       ("ang_vel kp (4e-2, 4e-2, 8e-2), ki (5e-7, 5e-7, 2.7e-4), control every sub-step", make_cfg(assign=LATER)),
+                       ("ang_vel kp (4e-2, 4e-2, 8e-2), ki (5e-7, 5e-7, 2.7e-4), 120 Hz control", make_cfg(assign=LATER, control_every_substep=0)),
+                       ("ang_vel kp (4e-2, 4e-2, 8e-2) alone, control every sub-step", make_cfg(assign={"ang_vel_kp": LATER["ang_vel_kp"]})),
+                       ("ang_vel kp (4e-2, 4e-2, 8e-2) alone, 120 Hz control", make_cfg(assign={"ang_vel_kp": LATER["ang_vel_kp"]}, control_every_substep=0)),
+                       ("ang_vel kp/ki later table + motor_tau x 0.4, control every sub-step", make_cfg({"motor_tau": 0.4}, assign=LATER)),
                        ("120 Hz control + ang_vel_kp_xy x 4", make_cfg({"ang_vel_kp_xy": 4}, control_every_substep=0)),
                        ("120 Hz control + ang_vel_kp_xy x 3, ang_pos_kp_xy x 1.25", make_cfg({"ang_vel_kp_xy": 3, "ang_pos_kp_xy": 1.25}, control_every_substep=0)),
                        ("120 Hz control + ang_pos_kp_xy x 2, total_thrust x 2", make_cfg({"ang_pos_kp_xy": 2, "total_thrust": 2}, control_every_substep=0)),
