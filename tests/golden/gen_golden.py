@@ -15,6 +15,7 @@ Outputs (inputs + expected outputs, all plain numeric arrays):
   geometry.npz       GeometryUtils cone / angle
   normalization.npz  normalize_inertial_data
   snapshot_buffer.npz  lidar_buffer.SnapshotBuffer / LiDARBufferManager on a scripted publication history
+  transform_features.npz  LidarMath.transform_features / neighbor_sphere_from_new_frame on 256 snapshot pairs (pybullet.rotateVector = a numpy stand-in)
   ref_level5_obs.npz decoded io_data0.h5 recorded observations (the only PyBullet-made numbers in the tree)
 """
 import importlib.util
@@ -306,6 +307,120 @@ def gen_snapshot_buffer():
     print("snapshot_buffer: lookups", int((found > 0).sum()), "of", found.size)
 
 
+def _rotate_vector_xyzw(q, v):
+    """The ONE primitive of transform_features that lives in pybullet: rotateVector(quaternion xyzw, vector) = q (0, v) q^-1 (sandwich
+    product, unit quaternion).  Stand-in for `pybullet.rotateVector` only; checked against analytic cases in gen_transform_features."""
+    x, y, z, w = (float(c) for c in q)
+    u, s = np.array([x, y, z]), w
+    v = np.asarray(v, float)
+    return tuple(2.0 * np.dot(u, v) * u + (s * s - np.dot(u, u)) * v + 2.0 * s * np.cross(u, v))
+
+
+def gen_transform_features():
+    """LidarMath.transform_features / reframe / neighbor_sphere_from_new_frame (lidar_math.py:53-83,186-260,324-352) — the COMPOSITION that
+    re-projects a neighbour's snapshot into the observer's frame — run by the reference on 256 (neighbour, own) snapshot pairs.  The only
+    thing the reference does not do itself here is the rotation primitive: `pybullet.rotateVector` is a stand-in (6 lines of numpy above,
+    asserted on identity, quarter turns about each axis, a composition and the xyzw order).  "Composition pinned modulo the rotation primitive"."""
+    import types
+
+    from core.dataclasses.angle_grid import LIDARSpec
+    from core.dataclasses.perception_snapshot import PerceptionSnapshot
+    from core.entities.entity_type import EntityType
+    from core.notification_system.topics_enum import TopicsEnum
+
+    # --- the stand-in against closed forms
+    h = np.sqrt(0.5)
+    R = _rotate_vector_xyzw
+    assert np.allclose(R([0, 0, 0, 1], [1, 2, 3]), [1, 2, 3])
+    assert np.allclose(R([0, 0, h, h], [1, 0, 0]), [0, 1, 0])          # +90 deg about z: x -> y
+    assert np.allclose(R([h, 0, 0, h], [0, 1, 0]), [0, 0, 1])          # +90 deg about x: y -> z
+    assert np.allclose(R([0, h, 0, h], [0, 0, 1]), [1, 0, 0])          # +90 deg about y: z -> x
+    assert np.allclose(R([0, 0, h, h], R([h, 0, 0, h], [0, 1, 0])), [0, 0, 1])   # composition: (x turn) then (z turn) leaves z alone
+    assert np.allclose(R([0, 0, 1, 0], [1, 0, 0]), [-1, 0, 0])         # xyzw order: (0,0,1,0) is a half turn about z, not the identity
+    pb = types.ModuleType("pybullet")
+    pb.rotateVector = _rotate_vector_xyzw
+
+    def tripwire(*a, **k):
+        raise AssertionError("only rotateVector may be reached")
+    pb.getMatrixFromQuaternion = tripwire
+    sys.modules["pybullet"] = pb
+    try:
+        lm = by_path("ref_lidar_math_tf", "core/entities/quadcopters/components/sensors/components/lidar_math.py")
+        # the reference's own KAT (math_test.py:11-69; its PerceptionSnapshot call passes a max_delta_step the dataclass no longer takes)
+        spec20 = LIDARSpec(theta_initial_radian=0, theta_final_radian=np.pi, phi_initial_radian=-np.pi, phi_final_radian=np.pi,
+                           resolution=16, n_channels=3, max_radius=20)
+        m20 = lm.LidarMath(spec20)
+        imu = TopicsEnum.INERTIAL_DATA_BROADCAST; lid = TopicsEnum.LIDAR_DATA_BROADCAST
+        nb = PerceptionSnapshot(topics={imu: {"position": [0.0, 0.0, 0.0], "quaternion": [0.0, 0.0, 0.0, 1.0]},
+                                        lid: {"features": [(0.5, np.pi / 2, 0.0, EntityType.LOITERINGMUNITION, 0, 1)]}},
+                                publisher_id=1, step=0, entity_type=EntityType.LOYALWINGMAN)
+        own = PerceptionSnapshot(topics={imu: {"position": [1.0, 0.0, 0.0], "quaternion": [0.0, 0.0, 0.0, 1.0]}}, publisher_id=2, step=0,
+                                 entity_type=EntityType.LOYALWINGMAN)
+        (kr, kt, kp, _, _), = m20.transform_features(nb, own)
+        assert np.isclose(kr, 0.45, atol=1e-2) and np.isclose(kt, np.pi / 2, atol=1e-2) and np.isclose(kp, 0.0, atol=1e-2)
+
+        spec = LIDARSpec(theta_initial_radian=0, theta_final_radian=np.pi, phi_initial_radian=-np.pi, phi_final_radian=np.pi,
+                         resolution=16, n_channels=3, max_radius=40.0)
+        math = lm.LidarMath(spec)
+        rng = np.random.RandomState(20251005)
+        N, F, P, D = 256, 11, 2, 12                      # level5_c1's shape: 2 wingmen, 12 drones, at most D - 1 features per snapshot
+        DELTA = 0.3                                      # the neighbour snapshot's normalized_delta (set on retrieval, lidar_buffer.py:143-150)
+        nb_pos = np.zeros((N, 3), np.float32); nb_quat = np.zeros((N, 4), np.float32)
+        own_pos = np.zeros((N, 3), np.float32); own_quat = np.zeros((N, 4), np.float32)
+        n_feat = np.zeros(N, np.int32); feats = np.zeros((N, F, 4), np.float64)       # r_hat, theta, phi, publisher slot
+        n_out = np.zeros(N, np.int32); out = np.zeros((N, F, 5), np.float64)
+        spheres = np.ones((N, 3, 13, 26), np.float32)
+
+        def quat(i):
+            if i % 2:   # a flying attitude: small roll / pitch, any yaw
+                r, p_, y = rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-np.pi, np.pi)
+                cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p_ / 2), np.sin(p_ / 2), np.cos(y / 2), np.sin(y / 2)
+                return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy])
+            q = rng.normal(size=4)
+            return q / np.linalg.norm(q)
+        self_echoes = collisions = clipped = 0
+        for i in range(N):
+            nb_pos[i] = rng.uniform(-6, 6, 3); own_pos[i] = rng.uniform(-6, 6, 3)
+            nb_quat[i] = quat(i); own_quat[i] = quat(i + 1)
+            if i == 0:  # the KAT's geometry at this spec's radius: target 20 m ahead of a neighbour at the origin, observer at x = 1
+                nb_pos[i] = 0; own_pos[i] = (1, 0, 0); nb_quat[i] = own_quat[i] = (0, 0, 0, 1)
+            k = int(rng.randint(0, F + 1)) if i else 1
+            slots = rng.permutation(np.r_[0, 2:D])[:k]     # publishers: the observer itself (slot 0: self echo) or an invader; never the neighbour
+            fl = []
+            for j, sl in enumerate(slots):
+                r, th, ph = rng.uniform(0.02, 0.45), rng.uniform(0, np.pi), rng.uniform(-np.pi, np.pi)
+                if i == 0: r, th, ph, sl = 0.5, np.pi / 2, 0.0, 5
+                if j and rng.rand() < 0.3:                 # a second target almost behind an earlier one: same cell from afar -> farther wins
+                    r0, th, ph = fl[0][0], fl[0][1] + rng.uniform(-0.01, 0.01), fl[0][2] + rng.uniform(-0.01, 0.01)
+                    r = r0 * rng.uniform(0.5, 1.6); th = float(np.clip(th, 0, np.pi))
+                if rng.rand() < 0.08: r = rng.uniform(0.8, 1.0)   # beyond the observer's range after the shift: r_hat clips to 1
+                et = EntityType.LOYALWINGMAN if sl < P else EntityType.LOITERINGMUNITION
+                fl.append((float(r), float(th), float(ph), et, 0.0, int(sl)))
+                feats[i, j] = (r, th, ph, sl)
+            n_feat[i] = k
+            nb = PerceptionSnapshot(topics={imu: {"position": nb_pos[i].tolist(), "quaternion": nb_quat[i].tolist()}, lid: {"features": fl}},
+                                    publisher_id=1, step=5, entity_type=EntityType.LOYALWINGMAN, normalized_delta=DELTA)
+            own = PerceptionSnapshot(topics={imu: {"position": own_pos[i].tolist(), "quaternion": own_quat[i].tolist()}}, publisher_id=0, step=7,
+                                     entity_type=EntityType.LOYALWINGMAN)
+            tf = math.transform_features(nb, own)
+            n_out[i] = len(tf)
+            for j, t in enumerate(tf):
+                out[i, j] = (t[0], t[1], t[2], t[3].value / 5, t[4])
+            self_echoes += k - len(tf); clipped += sum(t[0] >= 1.0 for t in tf)
+            sph = math.neighbor_sphere_from_new_frame(nb, own)
+            assert sph.shape == (3, 13, 26)
+            spheres[i] = sph
+            collisions += len(tf) - int((sph[0] < 1).sum()) - sum(t[0] >= 1.0 for t in tf)
+            assert np.all(sph[2][sph[0] < 1] == DELTA)
+        assert abs(out[0, 0, 0] - 19 / 40) < 1e-6
+    finally:
+        del sys.modules["pybullet"]
+    np.savez_compressed(os.path.join(OUT, "transform_features.npz"), nb_pos=nb_pos, nb_quat=nb_quat, own_pos=own_pos, own_quat=own_quat,
+                        n_feat=n_feat, feats=feats, n_out=n_out, out=out, spheres=spheres, delta=DELTA)
+    print("transform_features: pairs", N, "features", int(n_feat.sum()), "self echoes skipped", self_echoes, "cells lost to farther-wins", collisions,
+          "r_hat clipped to 1", clipped, "hit cells", int((spheres[:, 0] < 1).sum()))
+
+
 def gen_h5_fixture():
     """Decode src/core/rl_framework/utils/output/collect_and_save/io_data0.h5 without h5py
     (HDF5 v1 B-tree chunk index, one uncompressed chunk per sample)."""
@@ -361,6 +476,7 @@ if __name__ == "__main__":
     gen_geometry(); print("geometry ok")
     gen_normalization(); print("normalization ok")
     gen_snapshot_buffer()
+    gen_transform_features()
     gen_h5_fixture()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

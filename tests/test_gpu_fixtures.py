@@ -15,6 +15,7 @@ not with the oracle: te_set_state -> te_step / te_observe -> outputs + te_get_st
   gun.npz            Gun traces (can_fire, munition, cooldown, 3-float state)
   kamikaze.npz       KamikazeNavigator (air-combat-only and cone variants): next state + command
   normalization.npz  normalize_inertial_data
+  transform_features.npz  LidarMath.transform_features + add_features(invert) on 256 snapshot pairs (te_observe_stacked)
 
 Steps that must see exactly the fixture's positions run with cfg.substeps = 0, cfg.observe_lag = 0 (no physics: the IMU read is
 the loaded state)."""
@@ -447,3 +448,33 @@ def test_normalization_fixture_through_te_observe(golden):
     np.testing.assert_allclose(inertial[:, :12], g["out"], atol=1e-6)
     np.testing.assert_allclose(inertial[:, 12:15], np.tile([1.0, 0.0, 1.0], (n, 1)), atol=0)   # Gun().get_state() == [1, 0, 1]
     env.close()
+
+
+def test_transform_features_fixture_through_the_c_abi():
+    """tests/golden/transform_features.npz (the reference's LidarMath.transform_features / neighbor_sphere_from_new_frame on 256 snapshot pairs,
+    `pybullet.rotateVector` = the generator's numpy stand-in): env i carries pair i in its snapshot ring (te_set_state) and te_observe_stacked
+    must hand back the reference's re-projected sphere wherever it drew the neighbour — first hop on the GPU, compared with the FIXTURE.
+    Run on both implementations of the stacked observation (stack_view_kernel and the LDS fallback)."""
+    import os
+    import torch
+    from dronechase_amd import default_config
+    from oracle import te_oracle as O          # stack_draws only: which neighbour / age / shuffle env i draws (shared Philox stream)
+    from tests import _transform_fixture as TF
+    fx = TF.load()
+    cfg = default_config("level5_c1", n_envs=256, seed=11)
+    for mode in ("regs", "lds"):
+        if mode == "lds":
+            os.environ["TE_STACKED"] = "lds"
+        try:
+            g = _gpu(cfg)
+        finally:
+            os.environ.pop("TE_STACKED", None)
+        g.reset()
+        b = TF.build_state(cfg, g.get_state().cpu().numpy().view(np.uint32), fx)
+        g.set_state(torch.from_numpy(b.w.view(np.int32)).cuda())
+        stacked, mask, *_ = g.observe_stacked()
+        torch.cuda.synchronize()
+        episodes = [b.ei(e, "EPISODE") for e in range(256)]
+        info = TF.check(cfg, fx, stacked.cpu().numpy(), mask.cpu().numpy(), episodes, lambda e, ep: O.stack_draws(cfg, e, ep, TF.STEP, 0b11))
+        assert info["hit_cells_compared"] > 500, (mode, info)
+        g.close()

@@ -27,7 +27,7 @@ SCENARIOS = {
     "zone": ("exp03", dict(), dict(agent=(5, 0, 0), ally=(5, 1.5, 0), invaders=((5, 3, 0),)), [], 3, [1, 0, 0, 1]),
     "step_limit": ("exp03", dict(), dict(invaders=((0, 5, 3),)), [("ei", "STEP", 299)], 3, [0, 0, 0, 0]),
     "last_wave": ("exp03", dict(hit_prob=1.0), dict(), [("ei", "ROUND", 9)], 1, [0, 0, 0, 0]),
-    "chase": ("exp03", dict(), dict(ally=(0, 3, 3), invaders=((6, 0, 3),)), [], 6, [0, 1, 0, 0.7]),
+    "chase": ("exp03", dict(), dict(ally=(0, 3, 3), invaders=((6, 0, 3),)), [], 6, [0.3, 1, 0, 0.7]),
     "ally_dead": ("exp03", dict(), dict(ally=(0, 3, 3), invaders=((6, 0, 3), (0, 6, 3))), [("di", 1, "ARMED", 0), ("snap",)], 4, [0, 1, 0, 0.7]),
     "exp02_hit": ("exp02", dict(hit_prob=1.0), dict(), [], 3, [0, 0, 0, 0]),
     "exp04_frozen": ("exp04", dict(), dict(ally=(0, 3, 3), invaders=((6, 0, 3),)), [], 4, [1, 0, 0, 1]),

@@ -185,10 +185,10 @@ def main():
     print("motor-noise sigma per observable:", {n: float(f"{s:.4g}") for n, s in zip(names, sigma)})
     rows = []
     print("| candidate | chi2/dof | tilt1 | tilt2 | rate1 | speed1 | all within 1 +- 0.2 | chi2/dof (own noise) | -2 log L |\n|---|---|---|---|---|---|---|---|---|")
-    for label, cfg in (("recalled table, control every sub-step (the default)", base),
+    for label, cfg in (("recalled table (te_quad_preset 0; the default until round 2), control every sub-step", base),
                        ("update_control at 120 Hz (control_every_substep = 0)", make_cfg(control_every_substep=0)),
                        ("PID period 1/240 (control_dt = physics_dt)", make_cfg(control_dt=1 / 240)),
-                       ("recorded-fit preset (te_quad_preset 1: ang_vel_kp_xy x 6, motor_tau x 0.4)", make_cfg(preset=1)),
+                       ("recorded-fit table (te_quad_preset 1 = te_config_default since round 3: ang_vel_kp_xy x 6, motor_tau x 0.4)", make_cfg(preset=1)),
                        # round 3: a later published cf2x rate-loop table as recollected by the round-2 review (unverified): ang_vel kp / ki only
                        ("ang_vel kp (4e-2, 4e-2, 8e-2), ki (5e-7, 5e-7, 2.7e-4), control every sub-step", make_cfg(assign=LATER)),
                        ("ang_vel kp (4e-2, 4e-2, 8e-2), ki (5e-7, 5e-7, 2.7e-4), 120 Hz control", make_cfg(assign=LATER, control_every_substep=0)),
