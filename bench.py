@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--headline-only", action="store_true", help="skip the steady-state and all-armed windows")
     ap.add_argument("--steady-after", type=int, default=1000, help="rollout step at which the steady-state window starts")
     ap.add_argument("--steady-steps", type=int, default=200)
+    ap.add_argument("--null-stream", action="store_true", help="drive te_step from the legacy null stream instead of a stream of the bench's own")
     return ap.parse_args()
 
 
@@ -352,17 +353,26 @@ def main():
         torch.cuda.empty_cache()
         return out
 
-    if args.envs_per_gpu:       # an explicit shard size: per-GPU work fixed as N grows
-        out = measure(args.envs_per_gpu, args.headline_only, "weak")
-    else:                       # BASELINE.json's configuration: --total-envs in total, split over the ranks
-        if args.total_envs % world:
-            raise SystemExit(f"--total-envs {args.total_envs} does not split over {world} ranks")
-        out = measure(args.total_envs // world, args.headline_only, "weak" if world == 1 else "strong")
-        if world > 1 and not args.no_weak_block:
-            # the size one MI355X is efficient at, on every rank: what the node delivers when the caller has 65 536 envs PER GPU
-            wk = measure(args.total_envs, True, "weak")
-            if rank == 0:
-                out["weak_scaling"] = {k: wk[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "roofline", "roofline_env_step") if k in wk}
+    # te_step enqueues on the caller's stream (BatchedEnv passes torch's current one).  The bench drives it from a stream of its own, not
+    # from the legacy null stream: every launch into the null stream also orders itself against all blocking streams of the process,
+    # which costs ~2.5 us per launch on an MI355X (74.2 instead of 79.2 us per step, round 3, same box); --null-stream measures that.
+    import contextlib
+    lane = contextlib.nullcontext() if args.null_stream else torch.cuda.stream(torch.cuda.Stream(device))
+    with lane:
+        if args.envs_per_gpu:       # an explicit shard size: per-GPU work fixed as N grows
+            out = measure(args.envs_per_gpu, args.headline_only, "weak")
+        else:                       # BASELINE.json's configuration: --total-envs in total, split over the ranks
+            if args.total_envs % world:
+                raise SystemExit(f"--total-envs {args.total_envs} does not split over {world} ranks")
+            out = measure(args.total_envs // world, args.headline_only, "weak" if world == 1 else "strong")
+            if world > 1 and not args.no_weak_block:
+                # the size one MI355X is efficient at, on every rank: what the node delivers when the caller has 65 536 envs PER GPU
+                wk = measure(args.total_envs, True, "weak")
+                if rank == 0:
+                    out["weak_scaling"] = {k: wk[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "roofline", "roofline_env_step") if k in wk}
+        torch.cuda.current_stream(device).synchronize()
+    if rank == 0:
+        out.setdefault("config", {})["stream"] = "legacy null stream" if args.null_stream else "a non-default HIP stream (torch.cuda.Stream)"
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
