@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--headline-only", action="store_true", help="skip the steady-state and all-armed windows")
     ap.add_argument("--steady-after", type=int, default=1000, help="rollout step at which the steady-state window starts")
     ap.add_argument("--steady-steps", type=int, default=200)
-    ap.add_argument("--null-stream", action="store_true", help="drive te_step from the legacy null stream instead of a stream of the bench's own")
+    ap.add_argument("--own-stream", action="store_true", help="drive te_step from a stream of the bench's own instead of torch's current (null) stream")
     return ap.parse_args()
 
 
@@ -353,11 +353,11 @@ def main():
         torch.cuda.empty_cache()
         return out
 
-    # te_step enqueues on the caller's stream (BatchedEnv passes torch's current one).  The bench drives it from a stream of its own, not
-    # from the legacy null stream: every launch into the null stream also orders itself against all blocking streams of the process,
-    # which costs ~2.5 us per launch on an MI355X (74.2 instead of 79.2 us per step, round 3, same box); --null-stream measures that.
+    # te_step enqueues on the caller's stream (BatchedEnv passes torch's current one): the legacy null stream unless --own-stream.
+    # Interleaved A/B on one box (tools/ab_stream.sh, round 3): 851 / 851 / 861 M env-steps/s on the null stream against 848 / 855 / 846 M on a
+    # stream of the bench's own in the driver's window — no difference.
     import contextlib
-    lane = contextlib.nullcontext() if args.null_stream else torch.cuda.stream(torch.cuda.Stream(device))
+    lane = torch.cuda.stream(torch.cuda.Stream(device)) if args.own_stream else contextlib.nullcontext()
     with lane:
         if args.envs_per_gpu:       # an explicit shard size: per-GPU work fixed as N grows
             out = measure(args.envs_per_gpu, args.headline_only, "weak")
@@ -372,7 +372,7 @@ def main():
                     out["weak_scaling"] = {k: wk[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "roofline", "roofline_env_step") if k in wk}
         torch.cuda.current_stream(device).synchronize()
     if rank == 0:
-        out.setdefault("config", {})["stream"] = "legacy null stream" if args.null_stream else "a non-default HIP stream (torch.cuda.Stream)"
+        out.setdefault("config", {})["stream"] = "a non-default HIP stream (torch.cuda.Stream)" if args.own_stream else "torch's current stream (the legacy null stream)"
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libthreaten
 EXPORTS = (
     "te_config_default", "te_create", "te_destroy", "te_reset", "te_observe", "te_step", "te_random_actions",
     "te_state_words", "te_get_state", "te_set_state", "te_algorithmic_bytes_per_env_step", "te_profile_begin",
-    "te_profile_end", "te_debug_stamps", "te_abi_version", "te_last_error", "te_step_stacked", "te_observe_stacked", "te_observe_ally", "te_set_ally_actions", "te_wingman_info", "te_calculate_rounds", "te_observe_wingman", "te_set_wingman_actions", "te_quad_preset", "te_step_students",
+    "te_profile_end", "te_debug_stamps", "te_abi_version", "te_last_error", "te_step_stacked", "te_observe_stacked", "te_observe_ally", "te_set_ally_actions", "te_wingman_info", "te_calculate_rounds", "te_observe_wingman", "te_set_wingman_actions", "te_quad_preset", "te_step_students", "te_set_persistent_obs",
 )
 
 
@@ -64,6 +64,7 @@ def load() -> C.CDLL:
     L.te_algorithmic_bytes_per_env_step.argtypes = [C.POINTER(K.Config), C.POINTER(C.c_size_t)]
     L.te_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     L.te_profile_begin.argtypes = [vp, i32]
+    L.te_set_persistent_obs.argtypes = [vp, i32]
     L.te_profile_end.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)]
     if L.te_abi_version() != K.TE_ABI_VERSION:
         raise RuntimeError("libthreatengage.so ABI version differs from dronechase_amd.config")

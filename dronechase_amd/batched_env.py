@@ -124,6 +124,12 @@ class BatchedEnv:
                                           self._p(t[0]), self._p(t[1]), self._p(t[2]), self._p(t[3]), self._stream()), "te_step_stacked")
         return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
 
+    def set_persistent_obs(self, on: bool = True) -> None:
+        """level5 family: promise that nobody but the library writes the stacked observation buffer.  While the same buffer keeps being
+        passed (this object's own `stacked` / `_students` tensors are), a step rewrites only the cells that change instead of streaming
+        the whole [N,6,3,13,26] background (te_set_persistent_obs)."""
+        _lib.check(self.L.te_set_persistent_obs(self._h, 1 if on else 0), "te_set_persistent_obs")
+
     def step_students(self):
         """Level5DumbMultiObs (every wingman scripted): one env.step returning the student observation of EVERY pursuer and the teacher's
         action for it: (stacked [N,P,6,3,13,26], mask [N,P,6], inertial [N,P,15], last_action [N,P,4], active [N,P], reward, done, info)."""

@@ -133,18 +133,38 @@ TE_DEV void mul_hi_lo(uint32_t a, uint32_t m, uint32_t& hi, uint32_t& lo) {
   asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(prod) : "v"(a), "s"(m) : "vcc");
   hi = (uint32_t)(prod >> 32); lo = (uint32_t)prod;
 }
-TE_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+// a ^ b ^ k in ONE instruction: gfx950's three-input bit operation with the truth table of a three-way xor (the compiler emits two v_xor)
+TE_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t k) {
+#ifdef TE_NO_XOR3   // A/B builds only (tools/ab.sh)
+  return a ^ b ^ k;
+#else
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+  return r;
+#endif
+}
+// Philox4x32-R (Salmon et al., SC'11; Random123).  R = 10 everywhere a draw decides something (spawns, hits, neighbourhoods, actions);
+// R = 7 — the smallest round count the paper reports as Crush-resistant, with its own known-answer vectors in Random123 — for the motor
+// noise, which is 16 of a drone's 16 sub-step draws per env-step and ~12 % of the sub-step loop's issue cycles at R = 10.  The keys are
+// wave-uniform (cfg.seed).
+template <int ROUNDS>
+TE_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     uint32_t hi0, lo0, hi1, lo1;
     mul_hi_lo(c0, 0xD2511F53u, hi0, lo0);
     mul_hi_lo(c2, 0xCD9E8D57u, hi1, lo1);
-    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    uint32_t n0 = xor3(hi1, c1, k0), n2 = xor3(hi0, c3, k1);
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   return U4{c0, c1, c2, c3};
 }
+TE_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) { return philox4x32<10>(c0, c1, c2, c3, k0, k1); }
+#ifndef TE_MOTOR_ROUNDS
+#define TE_MOTOR_ROUNDS 7   // (-DTE_MOTOR_ROUNDS=10: A/B builds only; the oracle draws with 7)
+#endif
+constexpr int kMotorNoiseRounds = TE_MOTOR_ROUNDS;
 enum { RNG_SPAWN_INVADER = 1, RNG_SPAWN_PURSUER = 2, RNG_HIT = 3, RNG_MOTOR = 4, RNG_ACTION = 5, RNG_RESPAWN = 6, RNG_STACK = 7 };
 // counter = { global env (low 32), purpose | slot<<8 | sub<<16 | global env (high 8)<<24, episode, index }
 TE_DEV U4 env_rng(const te_config& c, int env, uint32_t purpose, uint32_t slot, uint32_t sub, uint32_t episode,
@@ -294,13 +314,13 @@ TE_DEV float pid(float kp, float kiT, float kdT, float lim, float err, float& I,
   return clampf(fmaf(kp, err, fmaf(kdT, d, I)), -lim, lim);
 }
 
-// Motor noise: 4 standard normals per sub-step.  One Philox4x32-10 call (40 quarter-rate integer multiplies)
+// Motor noise: 4 standard normals per sub-step.  One Philox4x32-7 call (14 quarter-rate 32x32->64 multiplies)
 // serves TWO consecutive sub-steps: 128 bits = eight 16-bit uniforms = four Box-Muller pairs on the native
 // log / sqrt / sin / cos.  Sub-step `sub` uses words {x,y} when even, {z,w} when odd, of call index sub >> 1.
 // The two words travel into substep() as they are and become normals only at the motor stage, so that no
 // float noise registers are live across the IMU / controller half of the sub-step.
 TE_DEV U4 motor_noise_bits(const te_config& c, int env, int slot, uint32_t episode, uint32_t step_index, int sub) {
-  // Same value as env_rng(c, env, RNG_MOTOR, slot, sub >> 1, episode, step_index).  The empty asm statements make
+  // The counter and key of env_rng(c, env, RNG_MOTOR, slot, sub >> 1, episode, step_index), 7 rounds.  The empty asm statements make
   // the loop-invariant inputs opaque per call: otherwise the compiler hoists the invariant half of the first
   // Philox rounds and all 20 round keys out of the sub-step loop, into ~8 VGPRs and ~20 SGPRs that stay live
   // across it (97 -> 91 VGPRs, i.e. 4 -> 5 waves per SIMD, for three extra multiplies per call).
@@ -308,8 +328,8 @@ TE_DEV U4 motor_noise_bits(const te_config& c, int env, int slot, uint32_t episo
   asm volatile("" : "+s"(k0), "+s"(k1));
   asm volatile("" : "+v"(episode), "+v"(step_index), "+v"(env));
   const uint64_t g = (uint64_t)c.env_index_base + (uint64_t)env;
-  return philox4x32_10((uint32_t)g, RNG_MOTOR | ((uint32_t)slot << 8) | ((uint32_t)(sub >> 1) << 16) | ((uint32_t)(g >> 32) << 24),
-                       episode, step_index, k0, k1);
+  return philox4x32<kMotorNoiseRounds>((uint32_t)g, RNG_MOTOR | ((uint32_t)slot << 8) | ((uint32_t)(sub >> 1) << 16) | ((uint32_t)(g >> 32) << 24),
+                                       episode, step_index, k0, k1);
 }
 // `m2ln2_gain2` = -2 ln 2 * gain^2: the normals come out already multiplied by the noise gain.
 TE_DEV void motor_noise_from(uint32_t a, uint32_t b, float m2ln2_gain2, float nz[4]) {

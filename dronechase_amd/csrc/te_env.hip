@@ -836,6 +836,8 @@ struct te_env {
   // profiling (te_profile_begin / te_profile_end)
   std::vector<hipEvent_t> events;
   int prof_cap = 0, prof_used = 0;
+  // te_set_persistent_obs: cells patched by the previous stacked observation (StackParams::prev), and which buffer they describe
+  bool persist_on = false; uint16_t* prev_cells = nullptr; const float* last_stacked = nullptr; int prev_observers = 0, last_n_obs = 0;
   bool prof_markers = false;   // TE_PROF=markers: marker packets between the launches instead of the kernels' own start / stop events
 };
 
@@ -1078,6 +1080,7 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   (void)hipFree(e->p.stage_tab);
   if (e->p.snap) (void)hipFree(e->p.snap);
   if (e->p.ring) (void)hipFree(e->p.ring);
+  if (e->prev_cells) (void)hipFree(e->prev_cells);
   if (e->p.dbg) (void)hipFree(e->p.dbg);
   delete e;
 }
@@ -1231,7 +1234,11 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   // lane; the rest is split evenly over the fill waves.
   FillJob fill{nullptr, 0u, 0u, 0u};
   const size_t n_floats = (size_t)p.N * lidar_words_per_env;
-  if (obs_lidar) {
+  // persistent observation (te_set_persistent_obs): when this is the buffer the previous stacked observation went to, it still holds
+  // ones + the recorded cells, and only those are touched (no background stream); otherwise fill as usual and record
+  int persist = 0;
+  if (stack && e->persist_on && e->stack_regs && n_obs <= e->prev_observers) persist = (obs_lidar && obs_lidar == e->last_stacked && n_obs == e->last_n_obs) ? 1 : 2;
+  if (obs_lidar && persist != 1) {
     const size_t quads = n_floats >> 2;
     if (quads >= 4096 && quads < (1ull << 32)) {
       fill = FillJob{obs_lidar, (uint32_t)quads, (uint32_t)e->n_fill_waves, (quads >> 6) < (1u << 22) ? (uint32_t)e->fill_mode : 0u};  // the SGPR block offset is 32-bit: < 4 GB
@@ -1278,7 +1285,7 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
     ev_a = nullptr; ev_b = nullptr;
     // the first launch pushes this step's ring entries (all wingmen) and serves observer 0; te_step_students adds one launch per further wingman
     if (e->stack_regs) {  // one wave per (chunk, wingman) pushes this step's ring entries, then one 5-wave workgroup per chunk and observer
-      StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 1, 0, n_obs};
+      StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 1, 0, n_obs, persist, e->prev_cells};
       const unsigned push_waves = (unsigned)b2 * (unsigned)p.cfg.n_pursuers;
       if (e->stack_regs == 18) TE_LAUNCH((ring_push_kernel<18>), dim3(push_waves), dim3(64), 0, sp);
       else TE_LAUNCH((ring_push_kernel<37>), dim3(push_waves), dim3(64), 0, sp);
@@ -1290,12 +1297,13 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
       }
     } else
     for (int ob = 0; ob < n_obs; ++ob) {
-      StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, ob == 0 ? 1 : 0, ob, n_obs};
+      StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, ob == 0 ? 1 : 0, ob, n_obs, 0, nullptr};
       if (prof_ext && ob == n_obs - 1) ev_b = pev[3];
       TE_LAUNCH(stacked_kernel, dim3(b2), dim3(kStackThreads), e->stack_lds_bytes, sp, *stack);
     }
   }
 #undef TE_LAUNCH
+  if (stack) { e->last_stacked = persist ? obs_lidar : nullptr; e->last_n_obs = n_obs; }
   if (prof) { if (!prof_ext) TE_HIP(hipEventRecord(pev[3], st)); e->prof_used += 4; }
   TE_HIP(hipGetLastError());
   return 0;
@@ -1367,6 +1375,29 @@ __attribute__((visibility("default"))) int te_step_stacked(te_env* e, const floa
   const StackOut so{obs_stacked, obs_mask, terminal_stacked, terminal_mask};
   return step_impl(e, actions, obs_stacked, TE_OBS_STACKED_WORDS, obs_inertial, obs_last_action, reward, done, info, nullptr,
                    terminal_inertial, terminal_last_action, &so, stream);
+}
+
+// Persistent stacked observation (opt-in).  The caller promises that nobody but this library writes the obs_stacked buffer it passes to
+// te_step_stacked / te_step_students / te_observe_stacked.  While it keeps passing the SAME buffer, a step then rewrites only the cells
+// that change — the <= 5 (D - 1) cells per env the previous observation patched go back to one, the new ones are patched — instead of
+// streaming the whole [N,6,3,13,26] background (24 KB per env, 1.6 GB at 65 536 envs) and patching it; the buffer's content is bit for
+// bit what the dense path writes (tests/test_gpu_level5.py).  A different pointer (a rollout buffer that advances every step) falls back
+// to the dense path for that call.  Terminal buffers are always written densely (done envs only).  Served by stack_view_kernel
+// (up to 37 drones per env); TE_STACKED=lds ignores it.
+__attribute__((visibility("default"))) int te_set_persistent_obs(te_env* e, int32_t on) {
+  if (!e) return fail("te_set_persistent_obs: null env");
+  if (!e->p.ring) return fail("te_set_persistent_obs: this te_env was created without cfg.stacked_obs");
+  DeviceGuard guard(e->device);
+  e->last_stacked = nullptr;
+  e->persist_on = on != 0 && e->stack_regs != 0;
+  if (e->persist_on && !e->prev_cells) {
+    const int observers = all_scripted(e->p.cfg) ? e->p.cfg.n_pursuers : 1;   // te_step_students serves every wingman
+    const size_t bytes = (size_t)observers * TE_STACK_SPHERES * (size_t)e->p.D * (size_t)e->p.Npad * sizeof(uint16_t);
+    if (hipMalloc(&e->prev_cells, bytes) != hipSuccess) { e->prev_cells = nullptr; e->persist_on = false; return fail("te_set_persistent_obs: out of device memory"); }
+    TE_HIP(hipMemset(e->prev_cells, 0, bytes));
+    e->prev_observers = observers;
+  }
+  return 0;
 }
 
 // Level5DumbMultiObs.compute_info rows of every pursuer after the step (level5_dumb_multiobs.py:116-150): normalised IMU + gun state,
@@ -1442,7 +1473,9 @@ __attribute__((visibility("default"))) int te_observe_stacked(te_env* e, float* 
   } else {
     hipLaunchKernelGGL(observe_kernel, dim3(blocks), dim3(256), e->lds_bytes, st, p, ObsOut{nullptr, obs_inertial, obs_last_action});
   }
-  StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 0, 0, 1};
+  const int persist = (e->persist_on && e->stack_regs && e->prev_observers >= 1) ? 2 : 0;   // dense fill above; the cells are recorded for the next step
+  StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 0, 0, 1, persist, e->prev_cells};
+  e->last_stacked = persist ? obs_stacked : nullptr; e->last_n_obs = 1;
   if (e->stack_regs == 18) hipLaunchKernelGGL((stack_view_kernel<18>), dim3(blocks), dim3(kViewThreads), e->view_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
   else if (e->stack_regs == 37) hipLaunchKernelGGL((stack_view_kernel<37>), dim3(blocks), dim3(kViewThreads), e->view_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});
   else hipLaunchKernelGGL(stacked_kernel, dim3(blocks), dim3(kStackThreads), e->stack_lds_bytes, st, sp, StackOut{obs_stacked, obs_mask, nullptr, nullptr});

@@ -12,9 +12,17 @@
 // Same arithmetic, same helpers (spherical_of, rotate_by, draw_stack, ring layout) and the same order of every farther- / closer-wins
 // decision as stacked_kernel, which stays as the fallback for shapes beyond DM = 37 and behind TE_STACKED=lds.
 #pragma once
+#include <utility>
+
 #include "te_stacked.hpp"
 
 namespace te {
+
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): a loop the front end expands
+template <class F, int... Is>
+TE_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+TE_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 template <int DM>
 __global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
@@ -40,10 +48,12 @@ __global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
   const V3 me{__uint_as_float(snap(sr.pos() + 0 * D + pp)), __uint_as_float(snap(sr.pos() + 1 * D + pp)), __uint_as_float(snap(sr.pos() + 2 * D + pp))};
   const Q4 q = quat_of_euler(V3{__uint_as_float(snap(sr.euler() + 0 * P + pp)), __uint_as_float(snap(sr.euler() + 1 * P + pp)), __uint_as_float(snap(sr.euler() + 2 * P + pp))});
   const Q4 qi = inverse_of(q);
-  // ---- the sphere of wingman pp: (r_hat, theta, phi, cell) of every other armed drone
+  // ---- the sphere of wingman pp: (r_hat, theta, phi, cell) of every other armed drone.  The slot loops are expanded by the front end
+  // (static_for: one lambda instance per compile-time index), not by the loop unroller: at DM = 37 the 37 x 37 closer-wins loop is
+  // beyond the unroller's budget, it stayed a loop, the per-slot arrays were indexed at run time and went to scratch (640 B, round 2).
   float rh[DM], th[DM], ph[DM]; uint32_t cell[DM];
-#pragma unroll
-  for (int j = 0; j < DM; ++j) {
+  static_for<DM>([&](auto J) {
+    constexpr int j = decltype(J)::value;
     cell[j] = 0xFFFFFFFFu; rh[j] = 1.0f; th[j] = 0.0f; ph[j] = 0.0f;
     if (j < hi && j != pp && ((A >> j) & 1u)) {
       const V3 pj{__uint_as_float(snap(sr.pos() + 0 * D + j)), __uint_as_float(snap(sr.pos() + 1 * D + j)), __uint_as_float(snap(sr.pos() + 2 * D + j))};
@@ -52,30 +62,30 @@ __global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
       spherical_of(c, local, rh[j], th[j], ph[j], cl);
       cell[j] = (uint32_t)cl;
     }
-  }
+  });
   // ---- closer wins per cell (lidar_math.py:262-311), as in stacked_kernel: j CLAIMS its cell if it is in view with r_hat < 1; the kept
   // feature of a cell is its closest claimant (ties: lowest slot); cells appear in the entry in the order of their first claimant
   uint32_t* ent = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)env, pp, step);
   uint32_t n = 0u;
-#pragma unroll
-  for (int j = 0; j < DM; ++j) {
-    if (j >= hi) continue;   // wave-uniform
+  static_for<DM>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    if (j >= hi) return;   // wave-uniform
     const bool claim = cell[j] != 0xFFFFFFFFu && rh[j] < 1.0f;
     bool lead = claim;
     float br = rh[j], bt = th[j], bp = ph[j]; int bw = j;
-#pragma unroll
-    for (int k = 0; k < DM; ++k) {
-      if (k == j || k >= hi) continue;
+    static_for<DM>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      if (k == j || k >= hi) return;
       const bool same = claim && cell[k] == cell[j] && rh[k] < 1.0f;   // cell[k] == 0xFFFFFFFF never equals a claimed cell
       if (same && k < j) lead = false;
       if (same && (rh[k] < br || (rh[k] == br && k < bw))) { br = rh[k]; bt = th[k]; bp = ph[k]; bw = k; }
-    }
+    });
     if (lead) {
       const uint32_t meta = (uint32_t)(bw < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) | ((uint32_t)bw << 8);
       *reinterpret_cast<uint4*>(ent + TE_RING_HEADER_WORDS + 4 * n) = make_uint4(__float_as_uint(br), __float_as_uint(bt), __float_as_uint(bp), meta);
       n += 1u;
     }
-  }
+  });
   *reinterpret_cast<uint4*>(ent) = make_uint4((uint32_t)step, n, __float_as_uint(me.x), __float_as_uint(me.y));
   *reinterpret_cast<uint4*>(ent + 4) = make_uint4(__float_as_uint(me.z), __float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z));
   *reinterpret_cast<uint4*>(ent + 8) = make_uint4(__float_as_uint(q.w), 0u, 0u, 0u);
@@ -224,8 +234,36 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
   if (valid) {
     const uint32_t n = row(r.n(role), l);
     const uint32_t at = row(r.opos() + role, l);
-    float* basep = row(r.done(), l) ? o.t_stacked : o.stacked;
-    if (n != 0xFFFFFFFFu && at != 0xFFu && basep) {
+    const bool done = row(r.done(), l) != 0u;
+    float* basep = done ? o.t_stacked : o.stacked;
+    const bool mine = n != 0xFFFFFFFFu && at != 0xFFu;
+    if (p.persist && o.stacked) {
+      // Persistent observation: the main buffer is not refilled.  Every output sphere is owned by exactly one wave of the workgroup this
+      // step — the wave whose list lands there, or, for the spheres nobody writes (padding; all six of an auto-reset env, whose reset
+      // observation is empty), the wave whose role is the sphere's rank among the unused ones (mod 5) — and that wave alone sets the
+      // sphere's cells of the previous call back to one and records the new ones: same wave, same addresses, stores stay in issue order.
+      float* mainp = o.stacked + orow(l) * TE_OBS_STACKED_WORDS;
+      uint16_t* pv = p.prev + (size_t)ob * TE_STACK_SPHERES * (size_t)D * p.Npad + env;
+      uint32_t used = 0u;
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5) { const uint32_t a5 = row(r.opos() + s5, l); if (!done && row(r.n(s5), l) != 0xFFFFFFFFu && a5 != 0xFFu) used |= 1u << a5; }
+      int rank = 0;
+      for (int sphere = 0; sphere < TE_STACK_SPHERES; ++sphere) {
+        const bool is_mine = !done && mine && (int)at == sphere;
+        const bool unused = !((used >> sphere) & 1u);
+        const bool take = is_mine || (unused && (rank % 5) == role);
+        if (unused) rank += 1;
+        if (!take) continue;
+        uint16_t* ps = pv + (size_t)sphere * D * p.Npad;
+        if (p.persist == 1) {
+          const int cnt = (int)ps[0];
+          float* d0 = mainp + (size_t)sphere * TE_OBS_LIDAR_WORDS;
+          for (int i = 0; i < cnt; ++i) { float* d = d0 + ps[(size_t)(1 + i) * p.Npad]; d[0] = 1.0f; d[TE_LIDAR_CELLS] = 1.0f; d[2 * TE_LIDAR_CELLS] = 1.0f; }
+        }
+        if (!is_mine) ps[0] = 0;
+      }
+    }
+    if (mine && basep) {
       float* d0 = basep + orow(l) * TE_OBS_STACKED_WORDS + (size_t)at * TE_OBS_LIDAR_WORDS;
       const float tnorm = role == 0 ? 0.1f : (float)((row(r.dage(), l) >> (8 * (role - 1))) & 0xFFu) / (float)TE_RING_DEPTH;
       const int base = r.list(role);
@@ -233,6 +271,11 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
         const uint32_t w = row(base + 2 * f, l);
         float* d = d0 + (w & 0xFFFFu);
         d[0] = rowf(base + 2 * f + 1, l); d[TE_LIDAR_CELLS] = (float)(w >> 16) / 5.0f; d[2 * TE_LIDAR_CELLS] = tnorm;
+      }
+      if (p.persist && o.stacked && !done) {
+        uint16_t* ps = p.prev + ((size_t)ob * TE_STACK_SPHERES + at) * (size_t)D * p.Npad + env;
+        ps[0] = (uint16_t)n;
+        for (uint32_t f = 0; f < n; ++f) ps[(size_t)(1 + f) * p.Npad] = (uint16_t)(row(base + 2 * f, l) & 0xFFFFu);
       }
     }
   }

@@ -222,10 +222,11 @@ typedef struct te_config {
 
 enum { TE_IO_DEVICE = 0, TE_IO_HOST = 1 };
 enum { TE_REWARD_EXP03 = 0, TE_REWARD_L5_DUMB = 1, TE_REWARD_L5_C1 = 2 };
-/* quadrotor parameter presets (te_quad_preset).  RECALLED = PyFlyt 0.11.1's cf2x.yaml / cf2x.urdf as recorded in SURVEY.md
- * Appendix B (the default of every task); RECORDED_FIT = the same table with the smallest change that reproduces the only
- * PyBullet-made numbers in the reference tree (io_data0.h5: seven wingmen, two steps after a respawn) within its motor-noise
- * scatter — see DESIGN.md 5 and tools/physics_fit.py.  Neither is verified against the PyFlyt sources. */
+/* quadrotor parameter presets (te_quad_preset).  RECALLED = PyFlyt 0.11.1's cf2x.yaml / cf2x.urdf as recalled in SURVEY.md
+ * Appendix B (the default until round 2; chi^2 / dof 5.3 against the recording below); RECORDED_FIT = the same table with the
+ * fewest changed entries (ang_vel_kp roll / pitch x 6, motor_tau x 0.4) that reproduce the only PyBullet-made numbers in the
+ * reference tree (io_data0.h5: seven wingmen, two steps after a respawn) within their motor-noise scatter (chi^2 / dof 0.29) —
+ * THE DEFAULT OF EVERY TASK since round 3; see DESIGN.md 5 and tools/physics_fit.py.  Neither is verified against the PyFlyt sources. */
 enum { TE_QUAD_CF2X_RECALLED = 0, TE_QUAD_CF2X_RECORDED_FIT = 1 };
 
 /* ---- state blob (te_get_state / te_set_state) ----------------------------
@@ -374,6 +375,14 @@ int te_set_wingman_actions(te_env* env, int32_t wingman, const float* actions, v
  * describe the fresh episode; callers that want an episode's final rows read them with cfg.auto_reset = 0, as the
  * reference's evaluation loop does (evaluation_exp01_1bt_app_ready.py:80-96). */
 int te_wingman_info(te_env* env, int32_t* wingman_info, void* stream);
+
+/* Persistent stacked observation (opt-in, level5 family; no counterpart in the reference, whose FusedLIDAR.read_data builds a fresh
+ * numpy stack every call, fused_lidar.py:223-262).  on != 0: the caller promises that nobody but this library writes the obs_stacked
+ * buffer it passes to te_step_stacked / te_step_students / te_observe_stacked.  While the SAME pointer keeps coming, a call rewrites only
+ * the cells that change (the cells the previous observation patched go back to 1, the new ones are patched) instead of streaming the
+ * whole [N,6,3,13,26] background; the buffer ends up bit for bit as the dense path leaves it.  A different pointer (e.g. the slots of a
+ * rollout buffer) takes the dense path for that call.  Terminal buffers are always dense.  on == 0 (the default): every call is dense. */
+int te_set_persistent_obs(te_env* env, int32_t on);
 
 /* Synthetic random-action generator of the throughput harness
  * (apps/threatengage_runner/interactive/analyse.py:55-59): dir ~ U(-1,1)^3, mag ~ U(0,1),

@@ -93,10 +93,12 @@ typedef struct ote_env {
 enum { OTE_RNG_SPAWN_INVADER = 1, OTE_RNG_SPAWN_PURSUER = 2, OTE_RNG_HIT = 3, OTE_RNG_MOTOR = 4,
        OTE_RNG_ACTION = 5, OTE_RNG_RESPAWN = 6, OTE_RNG_STACK = 7 };
 
-static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+/* Philox4x32-R (Salmon et al., SC'11; Random123): R = 10 for every draw that decides something, R = 7 (the smallest Crush-resistant
+ * round count of the paper; Random123 ships known answers for it) for the motor noise */
+static void philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
   uint32_t k0 = key[0], k1 = key[1];
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < rounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -109,9 +111,11 @@ static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_r(ctr, key, out, 10); }
 OTE_API void ote_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
   philox4x32_10(ctr, key, out);
 }
+OTE_API void ote_philox4x32_7(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox4x32_r(ctr, key, out, 7); }
 
 /* uniform in [0,1): 24 high bits, exact in float and double */
 static real u01(uint32_t x) { return (real)(x >> 8) * (real)(1.0 / 16777216.0); }
@@ -374,14 +378,20 @@ static void integrate(const te_config* c, ote_drone* d, const real Fw[3], const 
   d->quat[0] = x / n; d->quat[1] = y / n; d->quat[2] = z / n; d->quat[3] = w / n;
 }
 
-/* Motors.physics_update noise: 4 standard normals per (env, slot, step, sub-step).  One Philox4x32-10 call
+/* Motors.physics_update noise: 4 standard normals per (env, slot, step, sub-step).  One Philox4x32-7 call
  * serves TWO consecutive sub-steps: its 128 bits are split into eight 16-bit uniforms = four Box-Muller
  * pairs (the reference draws np_random.randn(4) from an unseeded stream, quadcopter.py:137,181; any N(0,1)
  * source restates it).  Sub-step `sub` uses words {0,1} when even, {2,3} when odd, of call index sub >> 1. */
 static void motor_noise(const ote_env* E, int e, int slot, uint32_t step_index, int sub, real out[4]) {
   if (!E->cfg.motor_noise) { out[0] = out[1] = out[2] = out[3] = 0; return; }
   uint32_t r[4];
-  ote_rng(E, e, OTE_RNG_MOTOR, (uint32_t)slot, (uint32_t)(sub >> 1), (uint32_t)E->envs[e].episode, step_index, r);
+  {  /* the counter / key of ote_rng(E, e, OTE_RNG_MOTOR, slot, sub >> 1, episode, step_index), 7 rounds */
+    const uint64_t g = (uint64_t)E->cfg.env_index_base + (uint64_t)e;
+    const uint32_t ctr[4] = {(uint32_t)g, OTE_RNG_MOTOR | ((uint32_t)slot << 8) | ((uint32_t)(sub >> 1) << 16) | ((uint32_t)(g >> 32) << 24),
+                             (uint32_t)E->envs[e].episode, step_index};
+    const uint32_t key[2] = {(uint32_t)E->cfg.seed, (uint32_t)(E->cfg.seed >> 32)};
+    philox4x32_r(ctr, key, r, 7);
+  }
   const uint32_t a = r[(sub & 1) * 2 + 0], b = r[(sub & 1) * 2 + 1];
   const real k16 = (real)(1.0 / 65536.0);
   real r0 = sqrt((real)-2 * log(((real)(a & 0xFFFFu) + (real)0.5) * k16)), a0 = (real)2 * OTE_PI * ((real)(a >> 16) * k16);

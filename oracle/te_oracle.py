@@ -262,9 +262,9 @@ def _d(a):
     return np.ascontiguousarray(a, np.float64)
 
 
-def philox(ctr, key, precision="f64"):
+def philox(ctr, key, precision="f64", rounds=10):
     c = np.asarray(ctr, np.uint32); k = np.asarray(key, np.uint32); o = np.zeros(4, np.uint32)
-    lib(precision).ote_philox4x32_10(_p(c), _p(k), _p(o))
+    getattr(lib(precision), {10: "ote_philox4x32_10", 7: "ote_philox4x32_7"}[rounds])(_p(c), _p(k), _p(o))
     return o
 
 

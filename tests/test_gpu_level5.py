@@ -287,3 +287,63 @@ def test_heterogeneous_chunk_ring_matches_lds_fallback_and_oracle(task, monkeypa
         np.testing.assert_array_equal(rg_ring[ok][lv][:, 1], ro_ring[ok][lv][:, 1])     # kept features per entry: what the bug lost
     assert (~dirty).sum() > N // 2
     g.close(); h.close(); o.close()
+
+
+@pytest.mark.parametrize("task", ["level5", "level5_fusion", "level5_dumb"])
+def test_persistent_observation_is_bitwise_the_dense_one(task):
+    """te_set_persistent_obs: while the caller keeps passing the same stacked buffer, a step only sets the previously patched cells back to
+    one and patches the new ones (no 24 KB-per-env background stream).  The buffer must be bit for bit what the dense path writes, through
+    auto-resets (reset observation in the main buffer, terminal observation in its own), a buffer swap (dense fallback for that call) and a
+    te_observe_stacked in between; N is not a multiple of 64."""
+    torch = _gpu()
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    N = 328
+    cfg = default_config(task, n_envs=N, motor_noise=1, max_step=9, seed=13)
+    students = task == "level5_dumb"
+    dense, pers = BatchedEnv(cfg, "cuda:0"), BatchedEnv(cfg, "cuda:0")
+    pers.set_persistent_obs(True)
+    dense.reset(); pers.reset()
+
+    def both(t):
+        if students:
+            return dense.step_students(), pers.step_students()
+        a = dense.random_actions(6, t)
+        return dense.step_stacked(a), pers.step_stacked(a)
+
+    def same(ra, rb, t):
+        torch.cuda.synchronize()
+        for k, (x, y) in enumerate(zip(ra, rb)):
+            assert torch.equal(x, y), (t, k)
+        if not students:
+            d = dense.done != 0
+            if bool(d.any()):
+                assert torch.equal(dense.t_stacked[d], pers.t_stacked[d]) and torch.equal(dense.t_mask[d], pers.t_mask[d]), t
+    if not students:
+        same(dense.observe_stacked(), pers.observe_stacked(), -1)
+    dones = 0
+    for t in range(36):
+        ra, rb = both(t)
+        same(ra, rb, t)
+        dones += int((dense.done != 0).sum())
+        buf = rb[0]
+        if t == 5:
+            # the mode is really on: a cell nobody patches keeps whatever it holds (a dense step would have streamed a one over it) ...
+            flat = buf.view(-1)
+            idx = int(torch.nonzero(flat == 1.0)[-1])            # the last empty cell of the buffer
+            flat[idx] = 7.0
+            ra, rb = both(100 + t)
+            torch.cuda.synchronize()
+            if float(ra[0].view(-1)[idx]) == 1.0:                # (unless this very step put a feature there)
+                assert float(rb[0].view(-1)[idx]) == 7.0, "the persistent path did not run: the background was streamed"
+                rb[0].view(-1)[idx] = 1.0
+            same(ra, rb, 100 + t)
+        if t == 12:   # a different buffer (a rollout slot): garbage in, the dense path must overwrite all of it
+            if students: pers._students = (torch.full_like(pers._students[0], 0.5), *pers._students[1:])
+            else: pers.stacked = torch.full_like(pers.stacked, 0.5)
+        if t == 20 and not students:
+            same(dense.observe_stacked(), pers.observe_stacked(), 200)
+    assert dones >= N      # every env went through an auto-reset (max_step 9)
+    pers.set_persistent_obs(False)
+    same(*both(300), 300)
+    dense.close(); pers.close()

@@ -15,6 +15,11 @@ def test_philox_known_answers():
     assert list(O.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2)) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
     assert list(O.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0])) == \
         [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    # ... and philox4x32-7 (same file), the generator of the motor noise since round 3
+    assert list(O.philox([0, 0, 0, 0], [0, 0], rounds=7)) == [0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48]
+    assert list(O.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, rounds=7)) == [0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662]
+    assert list(O.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0], rounds=7)) == \
+        [0x4DFCCABA, 0x190A87F0, 0xC47362BA, 0xB6B5242A]
 
 
 @pytest.mark.parametrize("prec", PREC)
