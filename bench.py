@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--headline-only", action="store_true", help="skip the steady-state and all-armed windows")
     ap.add_argument("--steady-after", type=int, default=1000, help="rollout step at which the steady-state window starts")
     ap.add_argument("--steady-steps", type=int, default=200)
+    ap.add_argument("--persistent-obs", action="store_true", help="level5 family: te_set_persistent_obs (the stacked observation is updated in place: the caller passes the same buffer every step)")
     ap.add_argument("--own-stream", action="store_true", help="drive te_step from a stream of the bench's own instead of torch's current (null) stream")
     return ap.parse_args()
 
@@ -149,6 +150,8 @@ def main():
         Returns the JSON line's fields (meaningful on rank 0)."""
         cfg = default_config(args.task, n_envs=n_local, env_index_base=rank * n_local, **overrides)
         env = BatchedEnv(cfg, device)
+        if args.persistent_obs:
+            env.set_persistent_obs(True)
         # The inputs of the timed region are resident in HBM when it starts (one [N,4] action batch per step, generated on
         # the device by te_random_actions beforehand): the timed loop is te_step only.  Above 4 GiB of actions the batches
         # are generated step by step inside the loop instead.
@@ -318,7 +321,8 @@ def main():
                                        f"{'stacked-sphere LIDAR 6x3x13x26' if cfg.stacked_obs else 'own-sphere LIDAR 3x13x26'}), {world * n_local} envs in total = {n_local} envs per GPU, "
                                        f"16 physics sub-steps per env-step, random actions, motor noise {'on' if cfg.motor_noise else 'off'}, auto-reset on",
                            "task": args.task, "envs_per_gpu": n_local, "total_envs": world * n_local, "drone_slots_per_env": D,
-                           "armed_drones_per_env": armed, "parallelism": f"env-sharded x{world}, no collective"},
+                           "armed_drones_per_env": armed, "parallelism": f"env-sharded x{world}, no collective",
+                           "persistent_obs": bool(args.persistent_obs)},
                 "done_fraction_last_step": done_frac,
             }
             if n_prof:

@@ -125,9 +125,9 @@ class BatchedEnv:
         return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
 
     def set_persistent_obs(self, on: bool = True) -> None:
-        """level5 family: promise that nobody but the library writes the stacked observation buffer.  While the same buffer keeps being
-        passed (this object's own `stacked` / `_students` tensors are), a step rewrites only the cells that change instead of streaming
-        the whole [N,6,3,13,26] background (te_set_persistent_obs)."""
+        """Promise that nobody but the library writes the LIDAR observation buffers.  While the same buffer keeps being passed (this
+        object's own `lidar` / `stacked` / `_students` tensors are, unless step(out=...) names another one), a step rewrites only the
+        cells that change instead of streaming the whole background first (te_set_persistent_obs)."""
         _lib.check(self.L.te_set_persistent_obs(self._h, 1 if on else 0), "te_set_persistent_obs")
 
     def step_students(self):

@@ -441,6 +441,14 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
         }
       }
     }
+    if (valid && o.persist && o.obs.lidar) {   // persistent observation: which cells of the MAIN buffer hold a feature now (an auto-reset env shows the empty sphere)
+      uint16_t* pv = o.prev + env;
+      int n = 0;
+#pragma unroll
+      for (int j = 1; j < DM; ++j)
+        if (!to_terminal && ((owners >> j) & one)) { n += 1; pv[(size_t)n * p.Npad] = (uint16_t)cell[j]; }
+      pv[0] = (uint16_t)n;
+    }
   }
 
   // compute_reward (:423-515); Evaluation_Task.compute_reward returns 0 (evaluation_task.py:508-515)
@@ -676,6 +684,17 @@ TE_DEV uint32_t own_sphere_regs(const te_config& c, int D, const float (&px)[DM]
   }
   return owners;
 }
+// persistent observation: the cells of the main buffer that hold a feature after this step (see StepOut)
+template <int DM>
+TE_DEV void record_sphere_regs(const StepOut& o, int npad, int env, bool to_terminal, uint32_t owners, const uint32_t (&cell)[DM]) {
+  if (!o.persist || !o.obs.lidar) return;
+  uint16_t* pv = o.prev + env;
+  int n = 0;
+#pragma unroll
+  for (int j = 1; j < DM; ++j)
+    if (!to_terminal && ((owners >> j) & 1u)) { n += 1; pv[(size_t)n * npad] = (uint16_t)cell[j]; }
+  pv[0] = (uint16_t)n;
+}
 template <int DM>
 TE_DEV void patch_sphere_regs(const te_config& c, float* __restrict__ dst, int env, int P, uint32_t owners, const uint32_t (&cell)[DM], const float (&rhat)[DM]) {
   if (!dst) return;
@@ -834,7 +853,7 @@ __global__ __launch_bounds__(64) void engage_stage02_kernel(Params p, const floa
     if (o.term.last_action) reinterpret_cast<float4*>(o.term.last_action)[env] = act;
   }
   terminal_tiles(c, o.term.lidar, to_terminal, lane);
-  if (valid) patch_sphere_regs<DM>(c, to_terminal ? o.term.lidar : o.obs.lidar, env, P, owners, cell, rhat);
+  if (valid) { patch_sphere_regs<DM>(c, to_terminal ? o.term.lidar : o.obs.lidar, env, P, owners, cell, rhat); record_sphere_regs<DM>(o, p.Npad, env, to_terminal, owners, cell); }
   // on_step_end: killed invaders come back (stages.py:167-174); last_offsets = current_offsets
   auto set_pos = [&](int s, V3 w) {
 #pragma unroll
@@ -941,7 +960,7 @@ __global__ __launch_bounds__(64) void engage_stage01_kernel(Params p, const floa
     if (o.term.last_action) reinterpret_cast<float4*>(o.term.last_action)[env] = act;
   }
   terminal_tiles(c, o.term.lidar, to_terminal, lane);
-  if (valid) patch_sphere_regs<DM>(c, to_terminal ? o.term.lidar : o.obs.lidar, env, 2, owners, cell, rhat);
+  if (valid) { patch_sphere_regs<DM>(c, to_terminal ? o.term.lidar : o.obs.lidar, env, 2, owners, cell, rhat); record_sphere_regs<DM>(o, p.Npad, env, to_terminal, owners, cell); }
   if (valid) {
     V3 p2 = pi;
     if (caught) {  // replace_invader_if_close (:147-154): rare, straight through the plane view (it reads the invader's motors and PID memories)

@@ -63,7 +63,11 @@ namespace te {
 typedef float te_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t te_u4 __attribute__((ext_vector_type(4)));
 #define TE_FILL_STORE(ptr) __builtin_nontemporal_store((te_f4){1.0f, 1.0f, 1.0f, 1.0f}, reinterpret_cast<te_f4*>(ptr))
-struct FillJob { float* lidar; uint32_t total_quads; uint32_t n_fill_waves; uint32_t mode; };
+// mode 0 / 1 / 2: stream ones over the whole buffer (pointer loop / scalar buffer loop / + s_setprio).  mode 3 (persistent observation,
+// te_set_persistent_obs): the buffer still holds the previous observation; wave w = list * nchunks + chunk sets the cells that observation
+// patched in output sphere `list` (= observer * 6 + sphere) of the chunk's 64 envs back to one — scattered stores that ride on the flights
+// of the same launch (which leave HBM idle) instead of sitting in the stacked-observation launch's critical path.
+struct FillJob { float* lidar; uint32_t total_quads; uint32_t n_fill_waves; uint32_t mode; const uint16_t* prev; uint32_t lists, list_rows, npad, n, tile_words; };
 
 // what kamikaze_update() reads of the other drones, through the wave's buffer resource
 struct NavView {
@@ -269,6 +273,19 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   const int nchunks = p.Npad >> 6;
   float4* fill_dst = reinterpret_cast<float4*>(fill.lidar);
   if (FILL) {
+    if (wave < (int)fill.n_fill_waves && fill.mode == 3) {  // ---- erase wave (persistent observation)
+      const uint32_t nch = fill.npad >> 6;
+      const uint32_t list = (uint32_t)wave / nch, env = ((uint32_t)wave - list * nch) * 64u + (uint32_t)lane;
+      if (env < fill.n) {
+        const uint16_t* __restrict__ pv = fill.prev + (size_t)list * fill.list_rows * fill.npad + env;
+        float* d0 = fill.lidar + ((size_t)env * fill.lists + list) * fill.tile_words;
+        const int cnt = (int)pv[0];
+        const bool time_plane = fill.tile_words > 2u * TE_LIDAR_CELLS;   // (cfg.lidar_channels == 2: no time plane)
+        for (int i = 0; i < cnt; ++i) { float* d = d0 + pv[(size_t)(1 + i) * fill.npad]; d[0] = 1.0f; d[TE_LIDAR_CELLS] = 1.0f; if (time_plane) d[2 * TE_LIDAR_CELLS] = 1.0f; }
+      }
+      TE_K1_END(1);
+      return;
+    }
     if (wave < (int)fill.n_fill_waves) {  // ---- fill wave
       // grid-stride: at any moment the fill waves write one contiguous n_fill_waves KB window, which the address
       // interleave spreads over every HBM channel
@@ -1195,6 +1212,7 @@ static int observe_device(te_env* e, float* obs_lidar, float* obs_inertial, floa
     return fail("te_observe: obs_lidar and obs_last_action must be 16-byte aligned");
   DeviceGuard guard(e->device);
   const int blocks = (e->p.N + kEPB - 1) / kEPB;
+  if (obs_lidar && obs_lidar == e->last_stacked) e->last_stacked = nullptr;   // persistent observation: this call rewrites the buffer without recording
   hipLaunchKernelGGL(observe_kernel, dim3(blocks), dim3(256), e->lds_bytes, (hipStream_t)stream, e->p, ObsOut{obs_lidar, obs_inertial, obs_last_action});
   TE_HIP(hipGetLastError());
   return 0;
@@ -1232,16 +1250,20 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   const bool noise = p.cfg.motor_noise != 0;
   // LIDAR background: N*1014 floats = quads float4 (+ <4 tail floats).  The drone waves write one float4 per
   // lane; the rest is split evenly over the fill waves.
-  FillJob fill{nullptr, 0u, 0u, 0u};
+  FillJob fill{nullptr, 0u, 0u, 0u, nullptr, 0u, 0u, 0u, 0u, 0u};
   const size_t n_floats = (size_t)p.N * lidar_words_per_env;
   // persistent observation (te_set_persistent_obs): when this is the buffer the previous stacked observation went to, it still holds
   // ones + the recorded cells, and only those are touched (no background stream); otherwise fill as usual and record
   int persist = 0;
-  if (stack && e->persist_on && e->stack_regs && n_obs <= e->prev_observers) persist = (obs_lidar && obs_lidar == e->last_stacked && n_obs == e->last_n_obs) ? 1 : 2;
-  if (obs_lidar && persist != 1) {
+  if (stack && e->persist_on && e->stack_regs && n_obs <= e->prev_observers) persist = (obs_lidar && obs_lidar == e->last_stacked && n_obs == e->last_n_obs) ? (n_obs > 1 ? 3 : 1) : 2;
+  if (!stack && e->persist_on && e->engage_regs && obs_lidar) persist = obs_lidar == e->last_stacked ? 1 : 2;   // te_step: the agent's own sphere
+  if (obs_lidar && persist == 1) {   // the cells of the previous observation go back to one next to this launch's flights
+    const uint32_t lists = stack ? (uint32_t)n_obs * TE_STACK_SPHERES : 1u;
+    fill = FillJob{obs_lidar, 0u, lists * (uint32_t)(p.Npad >> 6), 3u, e->prev_cells, lists, (uint32_t)p.D, (uint32_t)p.Npad, (uint32_t)p.N, (uint32_t)(lidar_words_per_env / (size_t)lists)};
+  } else if (obs_lidar && persist != 3) {
     const size_t quads = n_floats >> 2;
     if (quads >= 4096 && quads < (1ull << 32)) {
-      fill = FillJob{obs_lidar, (uint32_t)quads, (uint32_t)e->n_fill_waves, (quads >> 6) < (1u << 22) ? (uint32_t)e->fill_mode : 0u};  // the SGPR block offset is 32-bit: < 4 GB
+      fill = FillJob{obs_lidar, (uint32_t)quads, (uint32_t)e->n_fill_waves, (quads >> 6) < (1u << 22) ? (uint32_t)e->fill_mode : 0u, nullptr, 0u, 0u, 0u, 0u, 0u};  // the SGPR block offset is 32-bit: < 4 GB
       if (n_floats & 3) hipLaunchKernelGGL(fill_ones_kernel, dim3(1), dim3(64), 0, st, obs_lidar + (quads << 2), n_floats & 3);
     } else {  // tiny or huge buffers: plain fill kernel first
       hipLaunchKernelGGL(fill_ones_kernel, dim3(2048), dim3(256), 0, st, obs_lidar, n_floats);
@@ -1266,7 +1288,7 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   // the engage/observe kernel patches the agent's own sphere only in the classic layout; in stacked mode all LIDAR
   // output comes from stacked_kernel
   StepOut o{reward, done, info, ObsOut{stack ? nullptr : obs_lidar, obs_inertial, obs_last_action},
-            ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}};
+            ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}, e->prev_cells, stack ? 0 : persist};
   const bool contact = p.cfg.drone_contact != 0;   // its own instantiations: the contact pass would cost every launch ~150 VGPRs
   if (e->engage_regs == 1 && !contact) TE_LAUNCH((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, p, actions, o);
   else if (e->engage_regs == 2 && !contact) TE_LAUNCH((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, p, actions, o);
@@ -1303,7 +1325,7 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
     }
   }
 #undef TE_LAUNCH
-  if (stack) { e->last_stacked = persist ? obs_lidar : nullptr; e->last_n_obs = n_obs; }
+  e->last_stacked = persist ? obs_lidar : nullptr; e->last_n_obs = n_obs;
   if (prof) { if (!prof_ext) TE_HIP(hipEventRecord(pev[3], st)); e->prof_used += 4; }
   TE_HIP(hipGetLastError());
   return 0;
@@ -1377,22 +1399,22 @@ __attribute__((visibility("default"))) int te_step_stacked(te_env* e, const floa
                    terminal_inertial, terminal_last_action, &so, stream);
 }
 
-// Persistent stacked observation (opt-in).  The caller promises that nobody but this library writes the obs_stacked buffer it passes to
-// te_step_stacked / te_step_students / te_observe_stacked.  While it keeps passing the SAME buffer, a step then rewrites only the cells
-// that change — the <= 5 (D - 1) cells per env the previous observation patched go back to one, the new ones are patched — instead of
-// streaming the whole [N,6,3,13,26] background (24 KB per env, 1.6 GB at 65 536 envs) and patching it; the buffer's content is bit for
-// bit what the dense path writes (tests/test_gpu_level5.py).  A different pointer (a rollout buffer that advances every step) falls back
-// to the dense path for that call.  Terminal buffers are always written densely (done envs only).  Served by stack_view_kernel
-// (up to 37 drones per env); TE_STACKED=lds ignores it.
+// Persistent observation (opt-in).  The caller promises that nobody but this library writes the observation buffer it passes (obs_lidar
+// of te_step; obs_stacked of te_step_stacked / te_step_students / te_observe_stacked).  While it keeps passing the SAME buffer, a step
+// rewrites only the cells that change: the cells the previous observation patched (<= D - 1 per sphere, recorded by the kernel that patched
+// them) go back to one — by erase waves of the sub-step launch, next to its flights — and the new ones are patched, instead of streaming
+// the whole background (4 KB per env for the own sphere, 24 KB for the stacked one) and patching it.  The buffer's content is bit for bit
+// what the dense path writes (tests/test_gpu_level5.py, tests/test_gpu_properties.py).  A different pointer (a rollout buffer that
+// advances every step) falls back to the dense path for that call.  Terminal buffers are always written densely (done envs only).
+// Served by the register kernels (engage_kernel / engage_stage0x_kernel, stack_view_kernel); TE_ENGAGE=lds / TE_STACKED=lds ignore it.
 __attribute__((visibility("default"))) int te_set_persistent_obs(te_env* e, int32_t on) {
   if (!e) return fail("te_set_persistent_obs: null env");
-  if (!e->p.ring) return fail("te_set_persistent_obs: this te_env was created without cfg.stacked_obs");
   DeviceGuard guard(e->device);
   e->last_stacked = nullptr;
-  e->persist_on = on != 0 && e->stack_regs != 0;
+  e->persist_on = on != 0 && (e->p.ring ? e->stack_regs != 0 : e->engage_regs != 0);   // the register kernels record what they patch; the LDS fallbacks stay dense
   if (e->persist_on && !e->prev_cells) {
-    const int observers = all_scripted(e->p.cfg) ? e->p.cfg.n_pursuers : 1;   // te_step_students serves every wingman
-    const size_t bytes = (size_t)observers * TE_STACK_SPHERES * (size_t)e->p.D * (size_t)e->p.Npad * sizeof(uint16_t);
+    const int observers = !e->p.ring ? 1 : all_scripted(e->p.cfg) ? e->p.cfg.n_pursuers : 1;   // te_step_students serves every wingman
+    const size_t bytes = (size_t)observers * (e->p.ring ? TE_STACK_SPHERES : 1) * (size_t)e->p.D * (size_t)e->p.Npad * sizeof(uint16_t);
     if (hipMalloc(&e->prev_cells, bytes) != hipSuccess) { e->prev_cells = nullptr; e->persist_on = false; return fail("te_set_persistent_obs: out of device memory"); }
     TE_HIP(hipMemset(e->prev_cells, 0, bytes));
     e->prev_observers = observers;

@@ -508,7 +508,9 @@ template <int FAMILY, class V> TE_DEV void reset_env(const te_config& c, const V
 struct ObsOut { float* lidar; float* inertial; float* last_action; };
 // floats of one own-sphere row: lidar_channels x 13 x 26 (3: distance, flag, time; 2 = the legacy layout without the time plane)
 __host__ __device__ inline int lidar_words(const te_config& c) { return (c.lidar_channels == 2 ? 2 : TE_LIDAR_CHANNELS) * TE_LIDAR_CELLS; }
-struct StepOut { float* reward; uint8_t* done; int32_t* info; ObsOut obs, term; };
+// prev / persist: persistent observation (te_set_persistent_obs) of the register engage kernels: persist != 0 = RECORD the cells patched
+// into obs.lidar, prev[i * Npad + env]: i = 0 the count, i = 1.. the cells (u16); the sub-step launch of the next call erases them
+struct StepOut { float* reward; uint8_t* done; int32_t* info; ObsOut obs, term; uint16_t* prev; int persist; };
 
 // LidarMath.cartesian_to_spherical + normalize + binning (lidar_math.py:24-34,93-96,128-137)
 TE_DEV void lidar_cell(const te_config& c, V3 local, int& cell, float& rhat) {

@@ -157,10 +157,12 @@ struct StackParams {
   int push;              // 1: te_step_stacked (push this step's entries, clear the ring of auto-reset envs); 0: te_observe_stacked
   int observer;          // whose FusedLIDAR.read_data this launch serves: 0 = the agent; te_step_students launches it once per wingman
   int n_obs;             // observers per env in the output buffers: 1 ([N,6,...]) or P ([N,P,6,...], te_step_students)
-  // persistent observation (te_set_persistent_obs; stack_view_kernel only).  0: the buffer was filled with ones by this step's fill waves,
-  // patch it.  2: the same, and RECORD which cells of every output sphere were patched.  1: the buffer still holds the previous call's
-  // observation (ones + the recorded cells): set those cells back to one, patch, record — nothing else of the 24 KB per env is touched.
-  // prev[((observer * 6 + sphere) * (D) + i) * Npad + env]: i = 0 the count, i = 1.. the cells (u16, env fastest: lanes read coalesced)
+  // persistent observation (te_set_persistent_obs; stack_view_kernel only).  0: patch the buffer the fill waves of this step's sub-step
+  // launch streamed ones over.  2: the same, and RECORD which cells of every output sphere were patched.  1: the buffer still held the
+  // previous call's observation and the sub-step launch's erase waves (FillJob mode 3) have set its recorded cells back to one: patch and
+  // record — nothing else of the 24 KB per env is touched.  3 (several observers per env, te_step_students): like 1, but the wave that
+  // owns an output sphere erases it in stack_view_kernel itself.
+  // prev[((observer * 6 + sphere) * D + i) * Npad + env]: i = 0 the count, i = 1.. the cells (u16, env fastest: lanes read coalesced)
   int persist;
   uint16_t* prev;
 };

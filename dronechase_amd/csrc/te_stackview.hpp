@@ -238,11 +238,12 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
     float* basep = done ? o.t_stacked : o.stacked;
     const bool mine = n != 0xFFFFFFFFu && at != 0xFFu;
     if (p.persist && o.stacked) {
-      // Persistent observation: the main buffer is not refilled.  Every output sphere is owned by exactly one wave of the workgroup this
-      // step — the wave whose list lands there, or, for the spheres nobody writes (padding; all six of an auto-reset env, whose reset
-      // observation is empty), the wave whose role is the sphere's rank among the unused ones (mod 5) — and that wave alone sets the
-      // sphere's cells of the previous call back to one and records the new ones: same wave, same addresses, stores stay in issue order.
-      float* mainp = o.stacked + orow(l) * TE_OBS_STACKED_WORDS;
+      // Persistent observation: the main buffer is all ones when this launch starts — streamed by the sub-step launch's fill waves
+      // (persist == 2), or, when it still held the previous observation, its recorded cells set back to one by that launch's erase waves
+      // (persist == 1).  Here the cells patched now are RECORDED per output sphere for the next call; the spheres nobody writes (padding;
+      // all six of an auto-reset env, whose reset observation is empty) get an empty record from the wave whose role is the sphere's rank
+      // among the unused ones (mod 5).  With several observers per env (te_step_students, persist == 3) the erase happens here instead, by
+      // the wave that owns the sphere: 43 008 erase waves in front of the flights cost that path more than they hid (3.47 vs 2.75 ms per step).
       uint16_t* pv = p.prev + (size_t)ob * TE_STACK_SPHERES * (size_t)D * p.Npad + env;
       uint32_t used = 0u;
 #pragma unroll
@@ -255,9 +256,9 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
         if (unused) rank += 1;
         if (!take) continue;
         uint16_t* ps = pv + (size_t)sphere * D * p.Npad;
-        if (p.persist == 1) {
+        if (p.persist == 3) {   // te_step_students: the owner of a sphere erases it here (same wave as the patches below: stores stay in issue order)
           const int cnt = (int)ps[0];
-          float* d0 = mainp + (size_t)sphere * TE_OBS_LIDAR_WORDS;
+          float* d0 = o.stacked + orow(l) * TE_OBS_STACKED_WORDS + (size_t)sphere * TE_OBS_LIDAR_WORDS;
           for (int i = 0; i < cnt; ++i) { float* d = d0 + ps[(size_t)(1 + i) * p.Npad]; d[0] = 1.0f; d[TE_LIDAR_CELLS] = 1.0f; d[2 * TE_LIDAR_CELLS] = 1.0f; }
         }
         if (!is_mine) ps[0] = 0;

@@ -376,12 +376,13 @@ int te_set_wingman_actions(te_env* env, int32_t wingman, const float* actions, v
  * reference's evaluation loop does (evaluation_exp01_1bt_app_ready.py:80-96). */
 int te_wingman_info(te_env* env, int32_t* wingman_info, void* stream);
 
-/* Persistent stacked observation (opt-in, level5 family; no counterpart in the reference, whose FusedLIDAR.read_data builds a fresh
- * numpy stack every call, fused_lidar.py:223-262).  on != 0: the caller promises that nobody but this library writes the obs_stacked
- * buffer it passes to te_step_stacked / te_step_students / te_observe_stacked.  While the SAME pointer keeps coming, a call rewrites only
- * the cells that change (the cells the previous observation patched go back to 1, the new ones are patched) instead of streaming the
- * whole [N,6,3,13,26] background; the buffer ends up bit for bit as the dense path leaves it.  A different pointer (e.g. the slots of a
- * rollout buffer) takes the dense path for that call.  Terminal buffers are always dense.  on == 0 (the default): every call is dense. */
+/* Persistent observation (opt-in; no counterpart in the reference, whose sensors build a fresh numpy array every call,
+ * fused_lidar.py:143-262).  on != 0: the caller promises that nobody but this library writes the LIDAR observation buffer it passes
+ * (obs_lidar of te_step; obs_stacked of te_step_stacked / te_step_students / te_observe_stacked).  While the SAME pointer keeps coming, a
+ * call rewrites only the cells that change (the cells the previous observation patched go back to 1, the new ones are patched) instead of
+ * streaming the whole background; the buffer ends up bit for bit as the dense path leaves it.  A different pointer (e.g. the slots of a
+ * rollout buffer) takes the dense path for that call.  Terminal buffers are always dense.  on == 0 (the default): every call is dense.
+ * The algorithmic bytes of such a step are the cells it touches, not the background: bench.py keeps the dense path as its headline. */
 int te_set_persistent_obs(te_env* env, int32_t on);
 
 /* Synthetic random-action generator of the throughput harness

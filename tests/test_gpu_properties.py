@@ -237,3 +237,49 @@ def test_long_rollout_statistics_match_the_oracle():
     assert acc["dones"][0] > 1000         # enough episode ends for the comparison to mean something
     for k, (x, y) in acc.items():
         assert abs(x - y) <= 0.05 * max(abs(x), 1.0), (k, x, y)
+
+
+@pytest.mark.parametrize("task,over", [("stage03", {}), ("stage02", {"n_invaders": 8}), ("stage01", {}), ("exp03", {"lidar_channels": 2})])
+def test_persistent_own_sphere_is_bitwise_the_dense_one(task, over):
+    """te_set_persistent_obs with te_step: the sub-step launch's erase waves set the cells of the previous observation back to one and the
+    engage kernel patches + records the new ones; no background stream.  Bit for bit the dense path, through auto-resets, a buffer swap
+    (dense fallback for that call: step(out=...)), a te_observe in between, and N not a multiple of 64."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    N = 1000
+    cfg = default_config(task, n_envs=N, seed=3, max_step=11, **over)
+    dense, pers = BatchedEnv(cfg, "cuda:0"), BatchedEnv(cfg, "cuda:0")
+    pers.set_persistent_obs(True)
+    dense.reset(); pers.reset()
+    other = (torch.full_like(pers.lidar, 0.25), torch.empty_like(pers.inertial), torch.empty_like(pers.last_action))
+    dones = hits = 0
+    for t in range(40):
+        a = dense.random_actions(2, t)
+        ra = dense.step(a)
+        rb = pers.step(a, out=other) if t in (14, 15, 22) else pers.step(a)     # 14 -> 15: the swapped buffer itself becomes persistent; 22: back and forth
+        torch.cuda.synchronize()
+        for k, (x, y) in enumerate(zip(ra, rb)):
+            assert torch.equal(x, y), (t, k)
+        d = dense.done != 0
+        if bool(d.any()):
+            assert torch.equal(dense.t_lidar[d], pers.t_lidar[d]) and torch.equal(dense.t_inertial[d], pers.t_inertial[d])
+        dones += int(d.sum()); hits += int((ra[0][:, 0] < 1).sum())
+        if t == 6:   # the mode is on: a cell nobody patches keeps what it holds
+            flat = pers.lidar.view(-1)
+            idx = int(torch.nonzero(flat == 1.0)[-1])
+            flat[idx] = 7.0
+            a2 = dense.random_actions(2, 1000)
+            ra, rb = dense.step(a2), pers.step(a2)
+            torch.cuda.synchronize()
+            if float(ra[0].view(-1)[idx]) == 1.0:
+                assert float(rb[0].view(-1)[idx]) == 7.0, "the persistent path did not run: the background was streamed"
+                rb[0].view(-1)[idx] = 1.0
+            assert torch.equal(ra[0], rb[0])
+        if t == 25:
+            for x, y in zip(dense.observe(), pers.observe()):
+                assert torch.equal(x, y)
+    assert dones >= N and hits > 1000
+    dense.close(); pers.close()

@@ -5,9 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dronechase_amd import default_config
 from dronechase_amd.batched_env import BatchedEnv
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+N = int(args[0]) if len(args) > 0 else 16384
+steps = int(args[1]) if len(args) > 1 else 100
 env = BatchedEnv(default_config("level5_dumb", n_envs=N), "cuda:0")
+if "--persistent-obs" in sys.argv:   # the observations are updated in place (te_set_persistent_obs): the same buffer every step
+    env.set_persistent_obs(True)
 env.reset()
 for _ in range(20):
     env.step_students()
