@@ -365,6 +365,20 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
   bool guard = fabsf(sarg) >= 0.99999f;
   if (CTRL == 2 && !CAPTURE) {
     // coasting sub-step: nobody looks at the angles
+  } else if (
+#ifdef TE_NO_EASY_ANGLES   // A/B builds only (tools/ab.sh)
+             false &&
+#endif
+             __builtin_amdgcn_ballot_w64(!(R.m22 > 0.0f && fabsf(R.m21) <= 0.4142135623730950f * R.m22 && fabsf(sarg) <= 0.5f)) == 0ull) {
+    // Every lane of the wave flies within 22.5 degrees of roll and 30 degrees of pitch (the cascade's tilt limit is 0.4 rad): both
+    // inverse functions are on their central branch, where fast_atan2 / fast_asin reduce to their odd polynomials — the same values,
+    // without the range reduction, the square root and the selects of the general form (wave-uniform test; ~20 VALU instructions)
+    const float t = R.m21 * rcp(R.m22);
+    roll = atan_poly(t);
+    const float z = sarg * sarg;
+    pitch = sarg + sarg * z * asin_poly(z);
+    float inv = rsq(R.m00 * R.m00 + R.m10 * R.m10);
+    cyaw = R.m00 * inv; syaw = R.m10 * inv;
   } else if (!guard) {
     roll = fast_atan2(R.m21, R.m22);
     pitch = fast_asin(sarg);
