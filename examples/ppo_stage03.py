@@ -30,10 +30,17 @@ def main():
     from dronechase_amd.ppo import PPO, PPOConfig
 
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    # TE_PPO_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (the ranks share devices round-robin, the gradient bucket crosses
+    # through the host); the real thing is nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("TE_PPO_BACKEND", "nccl")
+    local = local if backend == "nccl" else local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     env = BatchedEnv(default_config(args.task, n_envs=args.envs, env_index_base=rank * args.envs), dev)
     ppo = PPO(env, PPOConfig(n_steps=args.n_steps, batch_size=args.batch_size, n_epochs=args.epochs), seed=0)
     if rank == 0:
@@ -48,6 +55,12 @@ def main():
             n = args.n_steps * args.envs * world
             print(json.dumps({"iter": it, "env_steps": n, "collect_env_steps_per_s": n / (t1 - t0), "train_env_steps_per_s": n / (t2 - t0),
                               **{k: round(v, 5) for k, v in {**r, **u}.items()}}), flush=True)
+    if world > 1:   # every rank applied the same mean gradient to the same initial weights: the replicas must still be identical
+        flat = torch.cat([p.detach().reshape(-1) for p in ppo.policy.parameters()]).double()
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"world": world, "replicas_in_sync": bool(torch.equal(lo, hi)), "param_abs_sum": float(flat.abs().sum())}), flush=True)
     env.close()
     if world > 1:
         dist.destroy_process_group()

@@ -115,3 +115,17 @@ def test_bench_two_ranks_reports_the_strong_scaling_point():
     assert w["scaling"] == "weak" and w["config"]["envs_per_gpu"] == 8192 and w["config"]["total_envs"] == 16384
     assert abs(w["value"] - 16384 / (w["ms_per_step"] * 1e-3)) / w["value"] < 1e-6
     assert "cpu_baseline" not in d                               # rank 0 at N = 1 only
+
+
+def test_ppo_example_with_two_ranks_sharing_the_gpu():
+    """BASELINE config 5 rehearsed with N = 2: examples/ppo_stage03.py under torch.distributed.run, two ranks on the one GPU
+    (TE_PPO_BACKEND=gloo), each with its own env shard and rollout, ONE gradient all-reduce per minibatch; the replicas must end identical."""
+    out = _launch(2, [os.path.join(ROOT, "examples", "ppo_stage03.py"), "--envs", "512", "--iters", "2", "--n-steps", "8", "--batch-size", "1024",
+                      "--epochs", "2"], {"TE_PPO_BACKEND": "gloo"}, 900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    iters = [l for l in lines if "iter" in l]
+    assert [l["iter"] for l in iters] == [0, 1] and all(l["env_steps"] == 8 * 512 * 2 for l in iters)      # whole-job env-steps: both shards
+    assert all(np.isfinite(l["pg_loss"]) and np.isfinite(l["v_loss"]) for l in iters)
+    sync = [l for l in lines if "replicas_in_sync" in l]
+    assert len(sync) == 1 and sync[0]["world"] == 2 and sync[0]["replicas_in_sync"] is True and sync[0]["param_abs_sum"] > 0
