@@ -432,13 +432,15 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     if (valid && dst) {
       dst += (size_t)env * lidar_words(c);
       const bool time_plane = c.lidar_channels != 2;
+      // plane by plane, not hit by hit: the hits of one plane fall into the same 1.3 KB of the env's tile, and consecutive store
+      // instructions that stay within it drain faster (interleaved A/B, round 3: engage kernel 29.4 -> 28.7 us, 49.8 -> 47 us with every slot armed)
 #pragma unroll
-      for (int j = 1; j < DM; ++j) {
-        if ((owners >> j) & one) {
-          dst[cell[j]] = rhat[j];
-          dst[TE_LIDAR_CELLS + cell[j]] = (float)(j < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
-          if (time_plane) dst[2 * TE_LIDAR_CELLS + cell[j]] = 0.1f;
-        }
+      for (int j = 1; j < DM; ++j) if ((owners >> j) & one) dst[cell[j]] = rhat[j];
+#pragma unroll
+      for (int j = 1; j < DM; ++j) if ((owners >> j) & one) dst[TE_LIDAR_CELLS + cell[j]] = (float)(j < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
+      if (time_plane) {
+#pragma unroll
+        for (int j = 1; j < DM; ++j) if ((owners >> j) & one) dst[2 * TE_LIDAR_CELLS + cell[j]] = 0.1f;
       }
     }
     if (valid && o.persist && o.obs.lidar) {   // persistent observation: which cells of the MAIN buffer hold a feature now (an auto-reset env shows the empty sphere)
@@ -701,12 +703,12 @@ TE_DEV void patch_sphere_regs(const te_config& c, float* __restrict__ dst, int e
   dst += (size_t)env * lidar_words(c);
   const bool time_plane = c.lidar_channels != 2;
 #pragma unroll
-  for (int j = 1; j < DM; ++j) {
-    if ((owners >> j) & 1u) {
-      dst[cell[j]] = rhat[j];
-      dst[TE_LIDAR_CELLS + cell[j]] = (float)(j < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
-      if (time_plane) dst[2 * TE_LIDAR_CELLS + cell[j]] = 0.1f;
-    }
+  for (int j = 1; j < DM; ++j) if ((owners >> j) & 1u) dst[cell[j]] = rhat[j];   // plane by plane (see engage_kernel)
+#pragma unroll
+  for (int j = 1; j < DM; ++j) if ((owners >> j) & 1u) dst[TE_LIDAR_CELLS + cell[j]] = (float)(j < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
+  if (time_plane) {
+#pragma unroll
+    for (int j = 1; j < DM; ++j) if ((owners >> j) & 1u) dst[2 * TE_LIDAR_CELLS + cell[j]] = 0.1f;
   }
 }
 // normalize_inertial_data + gun state of the agent (level4/components/utils/normalization.py:6-30,61-110; gun.py:101-113)

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
         float* d0 = fill.lidar + ((size_t)env * fill.lists + list) * fill.tile_words;
         const int cnt = (int)pv[0];
         const bool time_plane = fill.tile_words > 2u * TE_LIDAR_CELLS;   // (cfg.lidar_channels == 2: no time plane)
-        for (int i = 0; i < cnt; ++i) { float* d = d0 + pv[(size_t)(1 + i) * fill.npad]; d[0] = 1.0f; d[TE_LIDAR_CELLS] = 1.0f; if (time_plane) d[2 * TE_LIDAR_CELLS] = 1.0f; }
+        for (int pl = 0; pl < (time_plane ? 3 : 2); ++pl)   // plane by plane, like the patches
+          for (int i = 0; i < cnt; ++i) d0[pl * TE_LIDAR_CELLS + pv[(size_t)(1 + i) * fill.npad]] = 1.0f;
       }
       TE_K1_END(1);
       return;

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
         if (p.persist == 3) {   // te_step_students: the owner of a sphere erases it here (same wave as the patches below: stores stay in issue order)
           const int cnt = (int)ps[0];
           float* d0 = o.stacked + orow(l) * TE_OBS_STACKED_WORDS + (size_t)sphere * TE_OBS_LIDAR_WORDS;
-          for (int i = 0; i < cnt; ++i) { float* d = d0 + ps[(size_t)(1 + i) * p.Npad]; d[0] = 1.0f; d[TE_LIDAR_CELLS] = 1.0f; d[2 * TE_LIDAR_CELLS] = 1.0f; }
+          for (int i = 0; i < cnt; ++i) { float* d = d0 + ps[(size_t)(1 + i) * p.Npad]; d[0] = 1.0f; d[TE_LIDAR_CELLS] = 1.0f; d[2 * TE_LIDAR_CELLS] = 1.0f; }   // (cell by cell: plane by plane re-reads the list, 2.99 vs 2.70 ms per te_step_students)
         }
         if (!is_mine) ps[0] = 0;
       }
@@ -268,11 +268,10 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
       float* d0 = basep + orow(l) * TE_OBS_STACKED_WORDS + (size_t)at * TE_OBS_LIDAR_WORDS;
       const float tnorm = role == 0 ? 0.1f : (float)((row(r.dage(), l) >> (8 * (role - 1))) & 0xFFu) / (float)TE_RING_DEPTH;
       const int base = r.list(role);
-      for (uint32_t f = 0; f < n; ++f) {
-        const uint32_t w = row(base + 2 * f, l);
-        float* d = d0 + (w & 0xFFFFu);
-        d[0] = rowf(base + 2 * f + 1, l); d[TE_LIDAR_CELLS] = (float)(w >> 16) / 5.0f; d[2 * TE_LIDAR_CELLS] = tnorm;
-      }
+      // plane by plane (see engage_kernel: consecutive stores that stay within one plane of the tile drain faster)
+      for (uint32_t f = 0; f < n; ++f) d0[row(base + 2 * f, l) & 0xFFFFu] = rowf(base + 2 * f + 1, l);
+      for (uint32_t f = 0; f < n; ++f) { const uint32_t w = row(base + 2 * f, l); d0[TE_LIDAR_CELLS + (w & 0xFFFFu)] = (float)(w >> 16) / 5.0f; }
+      for (uint32_t f = 0; f < n; ++f) d0[2 * TE_LIDAR_CELLS + (row(base + 2 * f, l) & 0xFFFFu)] = tnorm;
       if (p.persist && o.stacked && !done) {
         uint16_t* ps = p.prev + ((size_t)ob * TE_STACK_SPHERES + at) * (size_t)D * p.Npad + env;
         ps[0] = (uint16_t)n;
