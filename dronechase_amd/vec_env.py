@@ -97,7 +97,8 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
 
     def __init__(self, task: str = "stage03", num_envs: int = 1024, device: str = "cuda:0",
                  dome_radius: Optional[float] = None, rl_frequency: int = 15, GUI: bool = False, seed: int = 0,
-                 env_index_base: int = 0, output: str = "numpy", infos: str = "dicts", backend=None, **overrides):
+                 env_index_base: int = 0, output: str = "numpy", infos: str = "dicts", backend=None,
+                 persistent_obs: Optional[bool] = None, **overrides):
         if GUI:
             raise ValueError("GUI=True has no batched equivalent (the reference forces n_envs=1 with a PyBullet window)")
         if output not in ("numpy", "torch") or infos not in ("dicts", "lazy"):
@@ -109,6 +110,13 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
             from .batched_env import BatchedEnv  # imports torch; fails loudly without a GPU
             backend = BatchedEnv(self.cfg, device)
         self.backend = backend
+        # te_set_persistent_obs: the LIDAR observation is updated in place instead of being streamed whole every step.  With numpy output
+        # the device buffers never leave this object (the caller gets host copies), so the promise "nobody else writes them" holds by
+        # construction and the mode is on unless asked otherwise; with torch output the caller holds the device tensors: opt-in.
+        if persistent_obs is None:
+            persistent_obs = output == "numpy"
+        if persistent_obs and hasattr(backend, "set_persistent_obs"):
+            backend.set_persistent_obs(True)
         self.num_envs = int(num_envs)
         self.stacked = bool(self.cfg.stacked_obs)  # level5: stacked_spheres + validity_mask instead of lidar
         self.observation_space = spaces.stacked_observation_space() if self.stacked else spaces.observation_space((int(self.cfg.lidar_channels), K.LIDAR_NTHETA, K.LIDAR_NPHI))
