@@ -50,6 +50,7 @@ struct Params {
   // (and by reset / set_state), read by the sub-step launch with a SCALAR load, so that a wave with nothing to fly
   // retires without a single vector memory operation
   uint64_t* slot_mask;  // [Npad / 64] (bit s for slot s < 64)
+  uint64_t* live_mask;  // [Npad / 64] bit s = SOME env of the chunk has slot s armed (dense or mixed): the rows the next engage launch requests
   // Slots armed in only a few envs of a chunk do not get a wave of their own (at 4.2 armed drones per env a rollout has
   // 7.6 armed slots per chunk, i.e. 56 % of the lanes of the flight waves would idle): their (env, slot) items share
   // MIXED waves of 64 items.  slot_mask then holds the slots flown densely; mixed_items[chunk * kMixedCap + i] =

@@ -43,10 +43,11 @@ namespace te {
 #define TE_ESTAMP(idx, wait) do {} while (0)
 #endif
 
-template <class V> TE_DEV void plan_slot_l4(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint64_t& dense, int& n) {
+template <class V> TE_DEV void plan_slot_l4(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint64_t& dense, int& n, uint64_t& live) {
   const unsigned long long b = __ballot(a);
   const int cnt = __popcll(b);
   if (cnt == 0) return;
+  live |= (uint64_t)1 << s;
   if (s == 0 || cnt >= dense_min || n + cnt > kMixedCap) { dense |= (uint64_t)1 << s; return; }
   if (a) items[n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | (s << 8));
   n += cnt;
@@ -230,10 +231,15 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   uint32_t armed_w[DM];
   int mun[PM], lf[PM];
   float fx[PM], fy[PM], fz[PM];   // FORMATION of the pursuers (the behaviour tree's MoveToFormation target)
+  // live: slots armed in at least one env of this chunk, left with the flight plan by the previous launch (or the census after a reset /
+  // te_set_state); the sub-step launch does not touch armed flags.  The four rows of an invader slot nobody has armed are not requested
+  // (a disarmed drone's position is never looked at: S masks it) — 5-8 of stage03's 11 slots are live in a rollout: 20 -> ~10 MB fetched
+  const uint32_t* __restrict__ lm32 = reinterpret_cast<const uint32_t*>(p.live_mask);
+  const uint64_t live = (uint64_t)__builtin_amdgcn_readfirstlane(lm32[2 * blockIdx.x]) | ((uint64_t)__builtin_amdgcn_readfirstlane(lm32[2 * blockIdx.x + 1]) << 32);
 #pragma unroll
   for (int s = 0; s < DM; ++s) {
     px[s] = py[s] = pz[s] = 0.0f; armed_w[s] = 0u;
-    if (s < D) {
+    if (s < D && (s < P || ((live >> s) & 1u))) {
       px[s] = __uint_as_float(ld(TE_D_OBS_POS, s)); py[s] = __uint_as_float(ld(TE_D_OBS_POS + 1, s)); pz[s] = __uint_as_float(ld(TE_D_OBS_POS + 2, s));
       armed_w[s] = ld(TE_D_ARMED, s);
     }
@@ -642,10 +648,10 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   TE_ESTAMP(9, 0);
   // ---- what the next sub-step launch has to fly for this chunk (post-spawn flags)
   {
-    uint64_t dense = 0u; int n = 0;
+    uint64_t dense = 0u, live = 0u; int n = 0;
     uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
-    for (int s = 0; s < D; ++s) plan_slot_l4<void>(items, p.dense_min, lane, s, valid && ((armed_post >> s) & one) != 0, dense, n);
-    if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = (uint32_t)n; }
+    for (int s = 0; s < D; ++s) plan_slot_l4<void>(items, p.dense_min, lane, s, valid && ((armed_post >> s) & one) != 0, dense, n, live);
+    if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = (uint32_t)n; p.live_mask[blockIdx.x] = live; }
   }
   TE_ESTAMP(10, 0);
   TE_ESTAMP(11, 1);   // ... and once every store has been acknowledged
@@ -903,7 +909,7 @@ __global__ __launch_bounds__(64) void engage_stage02_kernel(Params p, const floa
   {  // every armed slot flies as a dense wave outside the level4 family
     uint64_t dense = 0u;
     for (int s = 0; s < D; ++s) if (__ballot(valid && ((A >> s) & 1u))) dense |= (uint64_t)1 << s;
-    if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = 0u; }
+    if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = 0u; p.live_mask[blockIdx.x] = dense; }
   }
 }
 
@@ -989,7 +995,7 @@ __global__ __launch_bounds__(64) void engage_stage01_kernel(Params p, const floa
   {
     uint64_t dense = 0u;
     for (int s = 0; s < 3; ++s) if (__ballot(valid && ((A >> s) & 1u))) dense |= (uint64_t)1 << s;
-    if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = 0u; }
+    if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = 0u; p.live_mask[blockIdx.x] = dense; }
   }
 }
 

@@ -379,27 +379,28 @@ __global__ __launch_bounds__(256) void snapshot_kernel(Params p) {
 // slots armed in >= kDenseMin envs (and the agent's) fly as dense waves (bit in slot_mask), the armed (env, slot) pairs of
 // the other slots go to the mixed list in slot order.  `a` = this lane's env has drone s armed (false for lanes >= nvalid).
 template <int FAMILY>
-TE_DEV void plan_slot(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint64_t& dense, int& n) {
+TE_DEV void plan_slot(uint16_t* __restrict__ items, int dense_min, int lane, int s, bool a, uint64_t& dense, int& n, uint64_t& live) {
   const unsigned long long b = __ballot(a);
   const int cnt = __popcll(b);
   if (cnt == 0) return;
+  live |= (uint64_t)1 << s;   // armed somewhere in the chunk: the engage kernel requests this slot's rows (Params::live_mask)
   if (FAMILY != FAM_LEVEL4 || s == 0 || cnt >= dense_min || n + cnt > kMixedCap) { dense |= (uint64_t)1 << s; return; }
   // rank of this lane among the armed ones: v_mbcnt counts the set bits of b below the lane
   if (a) items[n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | (s << 8));
   n += cnt;
 }
-TE_DEV void plan_done(const Params& p, int chunk, int lane, uint64_t dense, int n) {
-  if (lane == 0) { p.slot_mask[chunk] = dense; p.mixed_count[chunk] = (uint32_t)n; }
+TE_DEV void plan_done(const Params& p, int chunk, int lane, uint64_t dense, int n, uint64_t live) {
+  if (lane == 0) { p.slot_mask[chunk] = dense; p.mixed_count[chunk] = (uint32_t)n; p.live_mask[chunk] = live; }
 }
 // rebuild slot_mask from the armed planes (after te_create / te_reset / te_set_state; during a rollout the
 // engage/observe kernel maintains it): one 64-thread block per chunk of 64 envs
 template <int FAMILY>
 __global__ __launch_bounds__(64) void census_kernel(Params p) {
   const int chunk = blockIdx.x, l = threadIdx.x, env = chunk * 64 + l;
-  uint64_t dense = 0u; int n = 0;
+  uint64_t dense = 0u, live = 0u; int n = 0;
   uint16_t* items = p.mixed_items + (size_t)chunk * kMixedCap;
-  for (int s = 0; s < p.D; ++s) plan_slot<FAMILY>(items, p.dense_min, l, s, env < p.N && p.dstate[((size_t)TE_D_ARMED * p.D + s) * p.Npad + env] != 0u, dense, n);
-  plan_done(p, chunk, l, dense, n);
+  for (int s = 0; s < p.D; ++s) plan_slot<FAMILY>(items, p.dense_min, l, s, env < p.N && p.dstate[((size_t)TE_D_ARMED * p.D + s) * p.Npad + env] != 0u, dense, n, live);
+  plan_done(p, chunk, l, dense, n, live);
 }
 // recompute the pending scripted commands from a freshly loaded state blob (te_set_state)
 __global__ __launch_bounds__(256) void prepare_commands_kernel(Params p) {
@@ -556,11 +557,11 @@ __global__ __launch_bounds__(THREADS) void engage_observe_kernel(Params p, const
     emit_rows(p.cfg, sm, r, o.obs, env0, nvalid, threadIdx.x, blockDim.x);
   }
   if (threadIdx.x < kEPB) {  // what the next sub-step launch has to fly for this chunk (post-spawn flags)
-    uint64_t dense = 0u; int n = 0;
+    uint64_t dense = 0u, live = 0u; int n = 0;
     uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
     for (int s = 0; s < p.D; ++s)
-      plan_slot<FAMILY>(items, p.dense_min, (int)threadIdx.x, s, (int)threadIdx.x < nvalid && sm[(r.armed() + s) * kEPB + threadIdx.x] != 0u, dense, n);
-    plan_done(p, (int)blockIdx.x, (int)threadIdx.x, dense, n);
+      plan_slot<FAMILY>(items, p.dense_min, (int)threadIdx.x, s, (int)threadIdx.x < nvalid && sm[(r.armed() + s) * kEPB + threadIdx.x] != 0u, dense, n, live);
+    plan_done(p, (int)blockIdx.x, (int)threadIdx.x, dense, n, live);
   }
   TE_STAMP(p, 500, 5);
   // terminal tiles of auto-reset envs (rare, block-uniform test): ones, drained, then patched
@@ -962,7 +963,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   te_env* e = new (std::nothrow) te_env();
   if (!e) return fail("te_create: out of host memory");
   e->device = device_id;
-  e->p.dstate = nullptr; e->p.estate = nullptr; e->p.slot_mask = nullptr; e->p.mixed_count = nullptr; e->p.mixed_items = nullptr; e->p.stage_tab = nullptr; e->p.snap = nullptr; e->p.ring = nullptr; e->p.dbg = nullptr;
+  e->p.dstate = nullptr; e->p.estate = nullptr; e->p.slot_mask = nullptr; e->p.live_mask = nullptr; e->p.mixed_count = nullptr; e->p.mixed_items = nullptr; e->p.stage_tab = nullptr; e->p.snap = nullptr; e->p.ring = nullptr; e->p.dbg = nullptr;
   // ONE failure path from here on: whatever has been allocated so far is released (te_destroy) before the error is returned
   auto bail = [&](const std::string& why) { te_destroy(e); return fail(why); };
 #define TE_HIP_OR_BAIL(x)                                                                              \
@@ -1014,7 +1015,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (dwords >= (1ull << 30)) return bail("te_create: n_envs * drones too large for one te_env (state planes are indexed with 32 bits); shard it");
   if (hipMalloc(&e->p.dstate, dwords * 4) != hipSuccess || hipMalloc(&e->p.estate, ewords * 4) != hipSuccess)
     return bail("te_create: hipMalloc failed");
-  if (hipMalloc(&e->p.slot_mask, (size_t)(e->p.Npad / 64) * 8) != hipSuccess || hipMalloc(&e->p.mixed_count, (size_t)(e->p.Npad / 64) * 4) != hipSuccess ||
+  if (hipMalloc(&e->p.slot_mask, (size_t)(e->p.Npad / 64) * 8) != hipSuccess || hipMalloc(&e->p.live_mask, (size_t)(e->p.Npad / 64) * 8) != hipSuccess || hipMalloc(&e->p.mixed_count, (size_t)(e->p.Npad / 64) * 4) != hipSuccess ||
       hipMalloc(&e->p.mixed_items, (size_t)(e->p.Npad / 64) * kMixedCap * sizeof(uint16_t)) != hipSuccess)
     return bail("te_create: hipMalloc failed");
   TE_HIP_OR_BAIL(hipMemsetAsync(e->p.mixed_count, 0, (size_t)(e->p.Npad / 64) * 4, nullptr));
@@ -1094,7 +1095,7 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   (void)hipFree(e->ally_scratch);
   (void)hipFree(e->zero_actions);
   (void)hipFree(e->hs.base);
-  (void)hipFree(e->p.slot_mask); (void)hipFree(e->p.mixed_count); (void)hipFree(e->p.mixed_items);
+  (void)hipFree(e->p.slot_mask); (void)hipFree(e->p.live_mask); (void)hipFree(e->p.mixed_count); (void)hipFree(e->p.mixed_items);
   (void)hipFree(e->p.stage_tab);
   if (e->p.snap) (void)hipFree(e->p.snap);
   if (e->p.ring) (void)hipFree(e->p.ring);
