@@ -67,7 +67,9 @@ struct Params {
 #ifdef TE_DEBUG_STAMPS
 __device__ unsigned long long* g_te_dbg = nullptr;
 #endif
-#if defined(TE_DEBUG_STAMPS) && !defined(TE_NO_STAMP)
+// (the LDS engage/observe kernel's own stamps need -DTE_LDS_STAMPS on top: next to this round's StepOut the compiler (ROCm 7.2) rejects the
+// flat null test of (p).dbg in those kernels with "Illegal instruction detected: V_CMP_NE_U32 $src_shared_base"; tools/k2_blocks.py, k2_stamps.py)
+#if defined(TE_DEBUG_STAMPS) && defined(TE_LDS_STAMPS) && !defined(TE_NO_STAMP)
 #define TE_STAMP(p, blk, idx)                                                                     \
   do {                                                                                            \
     if ((p).dbg && threadIdx.x == 0) {                                                            \

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-workgroup phase times of the engage/observe kernel over a rollout (needs a -DTE_DEBUG_STAMPS build):
+"""Per-workgroup phase times of the engage/observe kernel over a rollout (needs a -DTE_DEBUG_STAMPS -DTE_LDS_STAMPS build and TE_ENGAGE=lds; that combination does not compile with ROCm 7.2 since round 3, see te_device.hpp):
 which phase, in which blocks, sets the kernel's critical path."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase breakdown of one engage/observe workgroup (needs a -DTE_DEBUG_STAMPS build)."""
+"""Phase breakdown of one engage/observe workgroup (needs a -DTE_DEBUG_STAMPS -DTE_LDS_STAMPS build and TE_ENGAGE=lds; that combination does not compile with ROCm 7.2 since round 3, see te_device.hpp)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C, numpy as np, torch
