@@ -171,13 +171,26 @@ template <class V> TE_DEV uint32_t armed_mask(const V& v) {
 
 // spawn samplers ---------------------------------------------------------------------------------
 // Task.generate_positions (exp03_vFinal_task.py:584-608)
+// sin and cos of x in [0, pi] (the two angles of a spawn position): Cody-Waite reduction to |r| <= pi/4 around 0, pi/2 or pi and the
+// Cephes sinf / cosf minimax polynomials, < 1 ulp of the result's scale.  libm's sincosf carries its large-argument reduction along:
+// a respawning wave of the engage kernel paid ~0.3 us per call on its critical path (it is the kernel's slowest wave).
+TE_DEV void sincos_0_pi(float x, float& s, float& c) {
+  const int q = x < 0.7853981633974483f ? 0 : (x < 2.356194490192345f ? 1 : 2);   // nearest multiple of pi/2
+  const float y = (float)q * 2.0f;                                              // in units of pi/4
+  const float r = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+  const float z = r * r;
+  const float sr = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+  const float cr = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+  s = q == 0 ? sr : (q == 1 ? cr : -sr);
+  c = q == 0 ? cr : (q == 1 ? -sr : -cr);
+}
 TE_DEV V3 level4_position(const te_config& c, float r, float u_theta, float u_phi) {
   float theta = u_theta * kPi;
   float lower = fminf(c.born_min_z, r);
-  float min_phi = acosf(lower / r);
+  float min_phi = 0.5f * kPi - fast_asin(lower * rcp(r));   // acos on the polynomial asin of the sub-step loop (1e-7 abs)
   float phi = (r >= c.born_min_z) ? min_phi + u_phi * (0.5f * kPi - min_phi) : u_phi * (0.5f * kPi);
   float sph, cph, sth, cth;
-  sincosf(phi, &sph, &cph); sincosf(theta, &sth, &cth);
+  sincos_0_pi(phi, sph, cph); sincos_0_pi(theta, sth, cth);
   return V3{r * sph * cth, r * sph * sth, r * cph};
 }
 // L3Stage1.generate_positions (level3/components/stages.py:360-376)
