@@ -108,8 +108,30 @@ def cpu_baseline(task: str, overrides: dict, action_seed: int, seconds: float):
                       "PyBullet/PyFlyt are not installable here (no reference build possible)"}
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python3 bench.py --gpus N` launched plainly (no WORLD_SIZE in the environment) with N > 1: start the N ranks as a FRESH child
+    (`python -m torch.distributed.run`, one rank per GPU) before this process has touched the GPU, let its rank 0 print the one JSON line
+    on our stdout, and return its exit code.  Never an exec: a child process."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -126,18 +148,60 @@ def main():
         build_library()  # no-op when dronechase_amd/libthreatengage.so is up to date
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: dronechase_amd has no CPU fallback")
-    # TE_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
-    # devices round-robin; the reduction runs on host tensors).  The real thing is nccl (= RCCL), one rank per GPU.
+    # Control plane = barrier + max-over-ranks time; there is NO data-path collective (envs shard embarrassingly).  The default
+    # process group is gloo (host tensors: it cannot lose the run); on top of it one rank per GPU opens an RCCL ("nccl") group,
+    # proves it with one all-reduce, and from then on the barriers of the timed windows run over RCCL / xGMI.  If RCCL does not
+    # come up on every rank the run continues on gloo and the line says so (`control_plane`).
+    # TE_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share devices
+    # round-robin, no RCCL group).
     backend = os.environ.get("TE_BENCH_BACKEND", "nccl")
-    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    local_dev = local_rank % n_dev
     torch.cuda.set_device(local_dev)
     device = torch.device("cuda", local_dev)
+    rccl, control_plane = None, "single process"
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)  # barrier + max-over-ranks only; no data-path collective
-        else:
-            dist.init_process_group(backend)
+        import datetime
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        control_plane = "gloo (TE_BENCH_BACKEND=gloo)"
+        if backend == "nccl" and world > n_dev:
+            control_plane = f"gloo ({world} ranks share {n_dev} GPU(s): a rehearsal, RCCL needs one GPU per rank)"
+        elif backend == "nccl":
+            ok, why = 1, ""
+            try:
+                rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe, group=rccl)
+                torch.cuda.synchronize(device)
+                ok = int(probe.item() == world)
+            except Exception as exc:  # noqa: BLE001 - any RCCL failure falls back to the gloo control plane
+                ok, why = 0, f"{type(exc).__name__}: {exc}"[:200]
+            agree = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) == 1:
+                control_plane = "rccl (nccl backend: barrier + max-over-ranks; gloo default group underneath)"
+            else:
+                rccl, control_plane = None, f"gloo (RCCL group did not come up on every rank{': ' + why if why else ''})"
         dist.barrier()
+
+    def barrier():
+        if world > 1:
+            if rccl is not None:
+                dist.barrier(group=rccl, device_ids=[local_dev])
+            else:
+                dist.barrier()
+
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        if rccl is not None:
+            t = torch.tensor([x], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=rccl)
+        else:
+            t = torch.tensor([x], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     overrides = dict(motor_noise=0 if args.no_noise else 1, seed=args.seed)
     if args.n_invaders:
@@ -196,22 +260,19 @@ def main():
         n_batches = n_total if pregen else 1
 
         def timed(first: int, count: int) -> float:
-            """Wall time of `count` consecutive steps starting at rollout step `first`, bracketed by barrier + synchronize on both
-            sides, max over ranks.  Nothing but the step's own launches is enqueued in between (no event records)."""
-            if world > 1:
-                dist.barrier()
+            """Wall time of `count` consecutive steps starting at rollout step `first`: barrier + synchronize, the steps, synchronize — the
+            rank's clock stops THERE; the closing barrier and the max-over-ranks reduction come after it (a control-plane barrier costs tens
+            of microseconds, a 20-step window at a small shard is under a millisecond).  Nothing but the step's own launches is enqueued
+            in between (no event records)."""
+            barrier()
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             for i in range(count):
                 one_step((first + i) % n_batches if pregen else first + i)
             torch.cuda.synchronize(device)
-            if world > 1:
-                dist.barrier()
             el = time.perf_counter() - t0
-            t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
+            barrier()
+            return max_over_ranks(el)
 
         def kernel_times(first: int, count: int):
             """Average duration of the two kernels over the `count` steps starting at rollout step `first`: HIP events on the stream te_step
@@ -321,7 +382,7 @@ def main():
                                        f"{'stacked-sphere LIDAR 6x3x13x26' if cfg.stacked_obs else 'own-sphere LIDAR 3x13x26'}), {world * n_local} envs in total = {n_local} envs per GPU, "
                                        f"16 physics sub-steps per env-step, random actions, motor noise {'on' if cfg.motor_noise else 'off'}, auto-reset on",
                            "task": args.task, "envs_per_gpu": n_local, "total_envs": world * n_local, "drone_slots_per_env": D,
-                           "armed_drones_per_env": armed, "parallelism": f"env-sharded x{world}, no collective",
+                           "armed_drones_per_env": armed, "parallelism": f"env-sharded x{world}, no collective", "control_plane": control_plane,
                            "persistent_obs": bool(args.persistent_obs)},
                 "done_fraction_last_step": done_frac,
             }
@@ -368,7 +429,7 @@ def main():
         else:                       # BASELINE.json's configuration: --total-envs in total, split over the ranks
             if args.total_envs % world:
                 raise SystemExit(f"--total-envs {args.total_envs} does not split over {world} ranks")
-            out = measure(args.total_envs // world, args.headline_only, "weak" if world == 1 else "strong")
+            out = measure(args.total_envs // world, args.headline_only, "strong")   # the metric's configuration: total fixed, at every N incl. 1
             if world > 1 and not args.no_weak_block:
                 # the size one MI355X is efficient at, on every rank: what the node delivers when the caller has 65 536 envs PER GPU
                 wk = measure(args.total_envs, True, "weak")

@@ -845,6 +845,8 @@ struct te_env {
     float *actions = nullptr, *lidar = nullptr, *inertial = nullptr, *last_action = nullptr, *reward = nullptr;
     float *t_lidar = nullptr, *t_inertial = nullptr, *t_last_action = nullptr;
     uint8_t *done = nullptr, *mask = nullptr; int32_t* info = nullptr; uint32_t* blob = nullptr;
+    float* t_gather = nullptr;   // persistent observation under host I/O: where the done envs' terminal LIDAR rows are compacted (the
+                                 // observation staging must keep its content then); its own allocation, made by te_set_persistent_obs
   } hs;
   std::vector<int32_t> done_idx;   // host I/O: the done envs of the step, and the host landing zone of their terminal rows
   std::vector<char> done_rows;
@@ -1094,7 +1096,7 @@ __attribute__((visibility("default"))) void te_destroy(te_env* e) {
   (void)hipFree(e->p.estate);
   (void)hipFree(e->ally_scratch);
   (void)hipFree(e->zero_actions);
-  (void)hipFree(e->hs.base);
+  (void)hipFree(e->hs.base); (void)hipFree(e->hs.t_gather);
   (void)hipFree(e->p.slot_mask); (void)hipFree(e->p.live_mask); (void)hipFree(e->p.mixed_count); (void)hipFree(e->p.mixed_items);
   (void)hipFree(e->p.stage_tab);
   if (e->p.snap) (void)hipFree(e->p.snap);
@@ -1362,7 +1364,9 @@ __attribute__((visibility("default"))) int te_step(te_env* e, const float* actio
       if (n) {
         const size_t row[3] = {terminal_lidar ? lw : 0, terminal_inertial ? (size_t)60 : 0, terminal_last_action ? (size_t)16 : 0};
         const float* src[3] = {h.t_lidar, h.t_inertial, h.t_last_action};
-        float* tmp[3] = {h.lidar, h.inertial, h.last_action};
+        // (with the persistent observation the LIDAR staging IS the observation the next step patches in place: compact elsewhere)
+        float* tmp[3] = {e->persist_on && h.t_gather ? h.t_gather : h.lidar, h.inertial, h.last_action};
+        if (row[0] && tmp[0] == h.lidar) e->last_stacked = nullptr;   // the staging no longer holds the observation: next step is dense
         float* dst[3] = {terminal_lidar, terminal_inertial, terminal_last_action};
         e->done_rows.resize(n * (row[0] + row[1] + row[2]));
         TE_HIP(hipMemcpyAsync(h.info, idx.data(), n * 4, hipMemcpyHostToDevice, st));   // the info staging is free again too
@@ -1418,8 +1422,12 @@ __attribute__((visibility("default"))) int te_set_persistent_obs(te_env* e, int3
     const int observers = !e->p.ring ? 1 : all_scripted(e->p.cfg) ? e->p.cfg.n_pursuers : 1;   // te_step_students serves every wingman
     const size_t bytes = (size_t)observers * (e->p.ring ? TE_STACK_SPHERES : 1) * (size_t)e->p.D * (size_t)e->p.Npad * sizeof(uint16_t);
     if (hipMalloc(&e->prev_cells, bytes) != hipSuccess) { e->prev_cells = nullptr; e->persist_on = false; return fail("te_set_persistent_obs: out of device memory"); }
-    TE_HIP(hipMemset(e->prev_cells, 0, bytes));
-    e->prev_observers = observers;
+    e->prev_observers = observers;   // (no clear: the first call through a buffer always records before anything erases)
+  }
+  if (e->persist_on && host_io(e) && !e->hs.t_gather) {
+    if (hipMalloc(&e->hs.t_gather, (size_t)e->p.N * lidar_words(e->p.cfg) * 4) != hipSuccess) {
+      e->hs.t_gather = nullptr; e->persist_on = false; return fail("te_set_persistent_obs: out of device memory (terminal-row staging)");
+    }
   }
   return 0;
 }

@@ -41,3 +41,17 @@ def test_bench_line_has_the_contract_keys():
     assert d["steady_state"]["first_step"] >= 100
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s" and c["sample"]
+
+
+def test_plain_multi_gpu_command_starts_its_own_ranks_before_touching_the_gpu():
+    """No GPU here: `python bench.py --gpus 2` without WORLD_SIZE must hand over to torch.distributed.run (a child process), whose two
+    ranks then fail loudly for lack of an MI355X — and the plain command fails with them, printing no JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check (the GPU twin is tests/test_gpu_two_ranks.py)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--headline-only",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs an MI355X") >= 2 and "local_rank: 1" in out.stderr      # both ranks ran, under the elastic launcher
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -16,6 +16,7 @@ not with the oracle: te_set_state -> te_step / te_observe -> outputs + te_get_st
   kamikaze.npz       KamikazeNavigator (air-combat-only and cone variants): next state + command
   normalization.npz  normalize_inertial_data
   transform_features.npz  LidarMath.transform_features + add_features(invert) on 256 snapshot pairs (te_observe_stacked)
+  spawn_samplers.npz generate_positions of exp03 / stage02 and stage01's cube draws on the product's own Philox words (te_reset, wave advance, respawn)
 
 Steps that must see exactly the fixture's positions run with cfg.substeps = 0, cfg.observe_lag = 0 (no physics: the IMU read is
 the loaded state)."""
@@ -478,3 +479,17 @@ def test_transform_features_fixture_through_the_c_abi():
         info = TF.check(cfg, fx, stacked.cpu().numpy(), mask.cpu().numpy(), episodes, lambda e, ep: O.stack_draws(cfg, e, ep, TF.STEP, 0b11))
         assert info["hit_cells_compared"] > 500, (mode, info)
         g.close()
+
+
+def test_spawn_sampler_fixture_through_the_c_abi(golden):
+    """tests/golden/spawn_samplers.npz holds what the REFERENCE's generate_positions (exp03 r = 2 and r = 6, stage02 r = 1
+    and r in [2, 6]) and stage01's U(-1, 1)^3 draws make of the product's own Philox words; te_reset, the wave advance and the respawns of
+    te_step must land every drone there (positions read back with te_get_state)."""
+    from dronechase_amd import default_config
+    from tests import _spawn_samplers as SP
+    g = golden("spawn_samplers.npz")
+    eng = SP.Engine(make=_gpu, default_config=default_config, load=_load, state=_state, zeros=_zeros)
+    n = int(g["n_envs"])
+    assert SP.replay_exp03(g, eng) == n * (3 + sum(range(2, 10)))
+    assert SP.replay_stage02(g, eng) == n * (10 + 8 * len(g["s2_respawn_steps"]))
+    assert SP.replay_stage01(g, eng) == n * (3 + len(g["s1_catch_steps"]))

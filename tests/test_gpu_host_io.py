@@ -76,3 +76,48 @@ def test_host_io_rejects_what_it_does_not_serve():
     assert L.te_create(C.byref(default_config("level5", n_envs=64, io_location=K.IO_HOST)), 0, C.byref(h)) != 0
     assert b"TE_IO_HOST" in L.te_last_error()
     assert L.te_create(C.byref(default_config("exp03", n_envs=64, lidar_channels=4)), 0, C.byref(h)) != 0
+
+
+@pytest.mark.parametrize("task", ["stage03", "stage01"])
+def test_persistent_observation_under_host_io_is_bitwise_the_dense_one(task):
+    """te_set_persistent_obs with HOST pointers: the observation staging of the library is patched in place from step to step, so the
+    compaction of the done envs' terminal rows must not land in it (round-3 review: rows 0..n_done-1 kept stale terminal features).
+    Two te_envs on host pointers, one persistent, one dense, terminal buffers passed, auto-resets happening: every output equal bit for bit."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from dronechase_amd import _lib, config as K, default_config
+    N = 1500
+    L = _lib.load()
+    hs = []
+    for persistent in (1, 0):
+        cfg = default_config(task, n_envs=N, seed=9, io_location=K.IO_HOST)
+        if task == "stage03":
+            cfg.max_step = 12   # episodes end (and auto-reset) every dozen steps: many done rows per step
+        h = C.c_void_p()
+        _lib.check(L.te_create(C.byref(cfg), 0, C.byref(h)), "te_create")
+        _lib.check(L.te_set_persistent_obs(h, persistent), "te_set_persistent_obs")
+        _lib.check(L.te_reset(h, None, None), "te_reset")
+        hs.append(h)
+
+    def bufs():
+        return dict(lidar=np.zeros((N, 3, 13, 26), np.float32), inertial=np.zeros((N, 15), np.float32), la=np.zeros((N, 4), np.float32),
+                    tl=np.zeros((N, 3, 13, 26), np.float32), ti=np.zeros((N, 15), np.float32), ta=np.zeros((N, 4), np.float32),
+                    reward=np.zeros(N, np.float32), done=np.zeros(N, np.uint8), info=np.zeros((N, 4), np.int32))
+    a, b = bufs(), bufs()
+    actions = np.zeros((N, 4), np.float32)
+    n_done = 0
+    for s in range(80):
+        _lib.check(L.te_random_actions(hs[0], _p(actions), 31, s, None), "te_random_actions")
+        for h, o in ((hs[0], a), (hs[1], b)):
+            _lib.check(L.te_step(h, _p(actions), _p(o["lidar"]), _p(o["inertial"]), _p(o["la"]), _p(o["reward"]), _p(o["done"]), _p(o["info"]),
+                                 _p(o["tl"]), _p(o["ti"]), _p(o["ta"]), None), "te_step")
+        for k in ("lidar", "inertial", "la", "reward", "done", "info"):
+            assert np.array_equal(a[k], b[k]), (s, k)
+        d = a["done"].astype(bool)
+        n_done += int(d.sum())
+        for k in ("tl", "ti", "ta"):
+            assert np.array_equal(a[k][d], b[k][d]), (s, k)
+    assert n_done > (2000 if task == "stage03" else 0)
+    for h in hs:
+        L.te_destroy(h)

@@ -117,6 +117,25 @@ def test_bench_two_ranks_reports_the_strong_scaling_point():
     assert "cpu_baseline" not in d                               # rank 0 at N = 1 only
 
 
+def test_plain_bench_command_with_two_gpus_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (the shape of the N = 1 command): bench.py starts
+    torch.distributed.run itself as a fresh child before touching the GPU, relays rank 0's single JSON line and exits with the child's code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TE_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--total-envs", "8192",
+                          "--headline-only", "--no-cpu-baseline", "--no-weak-block"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["envs_per_gpu"] == 4096 and "weak_scaling" not in d
+    assert d["config"]["control_plane"].startswith("gloo")
+    # a failing child must fail the plain command too (WORLD_SIZE would not divide the envs)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total-envs", "8191",
+                          "--headline-only", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
 def test_ppo_example_with_two_ranks_sharing_the_gpu():
     """BASELINE config 5 rehearsed with N = 2: examples/ppo_stage03.py under torch.distributed.run, two ranks on the one GPU
     (TE_PPO_BACKEND=gloo), each with its own env shard and rollout, ONE gradient all-reduce per minibatch; the replicas must end identical."""
