@@ -223,6 +223,55 @@ TE_DEV float fast_asin(float x) {
   r = big ? 1.5707963267948966f - 2.0f * r : r;
   return copysignf(r, x);
 }
+// ---- exact arithmetic: functions that several kernels inline and whose results are compared BITWISE between them (engage_kernel vs
+// engage_slots_kernel, te_engage.hpp).  With -ffp-contract=fast the compiler chooses which multiply of a sum it fuses from the use counts
+// around the expression, i.e. from the kernel it inlines into; TE_EXACT switches contraction off for the enclosing block and the fused
+// multiply-adds are spelled out with xfma.
+#define TE_EXACT _Pragma("clang fp contract(off)")
+TE_DEV float xfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// sin and cos of a moderate x (|x| < ~1e4): Cody-Waite reduction by the nearest multiple of pi/2, Cephes sinf / cosf minimax polynomials
+// (< 1 ulp of the result's scale); no libm, no branches
+TE_DEV void x_sincos(float x, float& s, float& c) {
+  TE_EXACT
+  const float qf = rintf(x * 0.6366197723675814f);
+  const int q = (int)qf;
+  float r = xfma(qf, -1.5703125f, x);               // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188216e-8
+  r = xfma(qf, -4.837512969970703125e-4f, r);
+  r = xfma(qf, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float sr = xfma(r * z, xfma(xfma(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), r);
+  const float cr = xfma(z * z, xfma(xfma(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), xfma(-0.5f, z, 1.0f));
+  const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;   // sin(r + q pi/2): (s, c), (c, -s), (-s, -c), (-c, s)
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+// fast_asin / fast_atan2 above in Horner form on explicit fmas
+TE_DEV float x_asin(float x) {
+  TE_EXACT
+  const float a = fabsf(x);
+  const bool big = a > 0.5f;
+  const float z = big ? 0.5f * (1.0f - a) : a * a;
+  const float s = big ? fsqrt(z) : a;
+  const float pz = xfma(xfma(xfma(xfma(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f), z, 1.6666752422e-1f);
+  float r = xfma(s * z, pz, s);
+  r = big ? xfma(-2.0f, r, 1.5707963267948966f) : r;
+  return copysignf(r, x);
+}
+TE_DEV float x_atan2(float y, float x) {
+  TE_EXACT
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const bool hi = mn > 0.4142135623730950f * mx;
+  const float num = hi ? mn - mx : mn, den = hi ? mn + mx : mx;
+  const float t = den > 0.0f ? num * rcp(den) : 0.0f;
+  const float z = t * t;
+  const float pz = xfma(xfma(xfma(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+  float a = xfma(pz * z, t, t) + (hi ? 0.7853981633974483f : 0.0f);
+  a = ay > ax ? 1.5707963267948966f - a : a;
+  a = x < 0.0f ? kPi - a : a;
+  return copysignf(a, y);
+}
+
 struct V3 { float x, y, z; };
 TE_DEV float norm(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 TE_DEV V3 sub(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }

@@ -53,20 +53,61 @@ template <class V> TE_DEV void plan_slot_l4(uint16_t* __restrict__ items, int de
   n += cnt;
 }
 
+// ---- exact arithmetic ------------------------------------------------------------------------------------------------------------
+// engage_kernel (one wave per chunk) and engage_slots_kernel (te_engage_slots.hpp: one wave per (chunk, slot)) must produce the same bits:
+// a shard stepped by one and the whole env range stepped by the other are compared bitwise.  With -ffp-contract=fast the compiler picks
+// which multiply of a sum it fuses from the USE COUNTS around the expression, i.e. from the kernel the function was inlined into (first
+// slots build: 10 % of the LIDAR ranges one ulp apart).  The float arithmetic both kernels share is therefore written with contraction OFF
+// and every fused multiply-add spelled out (TE_EXACT, xfma, x_asin, x_atan2: te_device.hpp).
 // |a| and |a - b| on the native square root (1 ulp) instead of the correctly rounded sqrtf (~10 instructions each, ~45 calls)
-TE_DEV float fnorm(V3 a) { return fsqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
-TE_DEV float fdist(V3 a, V3 b) { return fnorm(sub(a, b)); }
-
+TE_DEV float fnorm(V3 a) { TE_EXACT return fsqrt(xfma(a.z, a.z, xfma(a.y, a.y, a.x * a.x))); }
+TE_DEV float fdist(V3 a, V3 b) { TE_EXACT return fnorm(V3{a.x - b.x, a.y - b.y, a.z - b.z}); }
+// the agent's inverse attitude from its IMU euler angles: getQuaternionFromEuler (te_device.hpp: quat_of_euler), conjugate / |q|^2,
+// btMatrix3x3::setRotation (te_device.hpp: rotation) — the same formulas with the contraction fixed
+TE_DEV M3 x_inverse_attitude(float roll, float pitch, float yaw) {
+  TE_EXACT
+  float sr, cr, sp, cp, sy, cy;
+  x_sincos(0.5f * roll, sr, cr); x_sincos(0.5f * pitch, sp, cp); x_sincos(0.5f * yaw, sy, cy);
+  const float a = sr * cp, b = cr * sp, d = cr * cp, e = sr * sp;
+  float qx = xfma(a, cy, -(b * sy)), qy = xfma(b, cy, a * sy), qz = xfma(d, sy, -(e * cy)), qw = xfma(d, cy, e * sy);
+  const float inv = 1.0f / sqrtf(xfma(qw, qw, xfma(qz, qz, xfma(qy, qy, qx * qx))));
+  qx *= inv; qy *= inv; qz *= inv; qw *= inv;
+  const float n2 = xfma(qw, qw, xfma(qz, qz, xfma(qy, qy, qx * qx)));
+  const float ix = -qx / n2, iy = -qy / n2, iz = -qz / n2, iw = qw / n2;
+  const float dd = xfma(iw, iw, xfma(iz, iz, xfma(iy, iy, ix * ix)));
+  const float s2 = 2.0f * rcp(dd);
+  const float xs = ix * s2, ys = iy * s2, zs = iz * s2;
+  const float wx = iw * xs, wy = iw * ys, wz = iw * zs;
+  const float xx = ix * xs, xy = ix * ys, xz = ix * zs;
+  const float yy = iy * ys, yz = iy * zs, zz = iz * zs;
+  return M3{1.0f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0f - (xx + yy)};
+}
+TE_DEV V3 x_mul(const M3& R, V3 v) {
+  TE_EXACT
+  return V3{xfma(R.m02, v.z, xfma(R.m01, v.y, R.m00 * v.x)), xfma(R.m12, v.z, xfma(R.m11, v.y, R.m10 * v.x)), xfma(R.m22, v.z, xfma(R.m21, v.y, R.m20 * v.x))};
+}
+// cmd_toward (te_logic.hpp) + Quadcopter.convert_command_to_setpoint (te_device.hpp: command_to_velocity): the behaviour tree's command
+TE_DEV void x_cmd_toward(V3 from, V3 to, float speed, float out[3]) {
+  TE_EXACT
+  const float dx = to.x - from.x, dy = to.y - from.y, dz = to.z - from.z;
+  const float n = sqrtf(xfma(dz, dz, xfma(dy, dy, dx * dx)));
+  const float inv = n > 0.0f ? 1.0f / n : 1.0f;  // zero vector stays zero (…air_combat_only.py:191-195)
+  const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+  const float m = sqrtf(xfma(uz, uz, xfma(uy, uy, ux * ux)));
+  const float inv2 = 1.0f / (m > 0.0f ? m : 1.0f);
+  out[0] = speed * (ux * inv2); out[1] = speed * (uy * inv2); out[2] = speed * (uz * inv2);
+}
 // lidar_cell (te_logic.hpp) on the native sqrt / rcp and the polynomial asin / atan2 of the sub-step loop (1e-7 abs): a tenth of
 // libm's acosf + atan2f instructions, which were a third of this kernel's straight-line path
 TE_DEV void lidar_cell_fast(const te_config& c, V3 local, int& cell, float& rhat) {
-  const float r2 = local.x * local.x + local.y * local.y + local.z * local.z;
+  TE_EXACT
+  const float r2 = xfma(local.z, local.z, xfma(local.y, local.y, local.x * local.x));
   float theta = 0.0f, phi = 0.0f, r = 0.0f;
   if (r2 != 0.0f) {
     const float inv = rsq(r2);
     r = r2 * inv;
-    theta = 0.5f * kPi - fast_asin(clampf(local.z * inv, -1.0f, 1.0f));
-    phi = fast_atan2(local.y, local.x);
+    theta = 0.5f * kPi - x_asin(clampf(local.z * inv, -1.0f, 1.0f));
+    phi = x_atan2(local.y, local.x);
   }
   rhat = clampf(r * rcp(c.lidar_radius), 0.0f, 1.0f);
   const int ti = min(max((int)(theta * (1.0f / kPi) * (float)TE_LIDAR_NTHETA), 0), TE_LIDAR_NTHETA - 1);
@@ -196,6 +237,7 @@ TE_DEV void drone_contact_pass(const Params& p, int env, bool valid, uint64_t A)
 
 template <int PM, int IM, bool CONTACT = false>
 __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+  TE_EXACT   // (see "exact arithmetic" above: the reward and the rows are computed by engage_slots_kernel too)
   constexpr int DM = PM + IM;
   using M = typename std::conditional<(DM > 32), uint64_t, uint32_t>::type;   // slot masks: 64 bits for Level5DumbMultiObs' 37 drones
   constexpr M one = 1;
@@ -365,12 +407,10 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   M owners = 0;
   uint32_t cell[DM]; float rhat[DM];
   {
-    const Q4 q = quat_of_euler(V3{ag[0], ag[1], ag[2]});
-    const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-    const M3 R = rotation(Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2});
+    const M3 R = x_inverse_attitude(ag[0], ag[1], ag[2]);
 #pragma unroll
     for (int j = 1; j < DM; ++j) {   // every slot is binned, armed or not (branch-free, as above); only armed ones may own a cell
-      int cj; lidar_cell_fast(c, mul(R, sub(V3{px[j], py[j], pz[j]}, apos)), cj, rhat[j]);
+      int cj; lidar_cell_fast(c, x_mul(R, sub(V3{px[j], py[j], pz[j]}, apos)), cj, rhat[j]);
       cell[j] = (uint32_t)cj;
       const bool in = ((A >> j) & one) != 0;
       M same = 0;           // the current owner of the same cell, if any (at most one)
@@ -635,8 +675,8 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
                   }
                 }
               }
-              cmd_toward(me, tp, c.ally_speed, out);
-            } else cmd_toward(me, V3{fx[q], fy[q], fz[q]}, c.ally_speed, out);
+              x_cmd_toward(me, tp, c.ally_speed, out);
+            } else x_cmd_toward(me, V3{fx[q], fy[q], fz[q]}, c.ally_speed, out);
           } else if (ext || c.ally_policy != TE_ALLY_FROZEN) {  // nobody / the caller's policy: the set-point persists
             out[0] = g.gf(TE_D_SETPOINT + 0, q); out[1] = g.gf(TE_D_SETPOINT + 1, q); out[2] = g.gf(TE_D_SETPOINT + 3, q);
           }
@@ -671,13 +711,11 @@ TE_DEV uint32_t own_sphere_regs(const te_config& c, int D, const float (&px)[DM]
                                 uint32_t A, uint32_t (&cell)[DM], float (&rhat)[DM]) {
   uint32_t owners = 0u;
   const V3 apos{px[0], py[0], pz[0]};
-  const Q4 q = quat_of_euler(V3{ag[0], ag[1], ag[2]});
-  const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-  const M3 R = rotation(Q4{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2});
+  const M3 R = x_inverse_attitude(ag[0], ag[1], ag[2]);
   cell[0] = 0u; rhat[0] = 1.0f;
 #pragma unroll
   for (int j = 1; j < DM; ++j) {
-    int cj; lidar_cell_fast(c, mul(R, sub(V3{px[j], py[j], pz[j]}, apos)), cj, rhat[j]);
+    int cj; lidar_cell_fast(c, x_mul(R, sub(V3{px[j], py[j], pz[j]}, apos)), cj, rhat[j]);
     cell[j] = (uint32_t)cj;
     const bool in = j < D && ((A >> j) & 1u) != 0u;
     uint32_t same = 0u; float r_owner = 2.0f;

@@ -1,0 +1,399 @@
+// te_engage_slots.hpp — the engage/observe step with ONE WAVE PER (chunk of 64 envs, drone slot): the small-shard form.
+//
+// engage_kernel (te_engage.hpp) gives every env one lane and every chunk one wave: ~2 000 straight-line VALU instructions per wave,
+// 11-17 us of one dependent chain, which is the whole kernel when a shard has fewer chunks than the chip has SIMDs (8 192 envs per GPU =
+// 128 waves for 1 024 SIMDs: the metric's 8-GPU shard).  Here a chunk is a workgroup of D waves; lane = env as before, so every plane
+// access stays one coalesced 256-byte row and "the other drones of my env" are the same lane of another wave's LDS row:
+//
+//   P1  wave s: its own slot's IMU position + armed flag, the agent's pose, the env counters (one round of independent loads; a pursuer
+//       wave also requests every live invader's row: its targeting needs no other wave) -> |p|, dome / origin flags, the LIDAR cell and
+//       range of its drone in the agent's frame; a pursuer wave: closest invader, shot (Philox only on the lanes that fire), explosion
+//       -> one LDS row each (flags, position, cell, range, pursuer record)                                              -> barrier 1
+//   P3  every wave, redundantly (a few dozen LDS reads): masks, kills, counters, termination, the next round / auto-reset decision;
+//       wave s alone: Quadcopter.disarm of its drone, closer-wins ownership of its LIDAR cell (the minimum of (range, slot) over the
+//       armed drones in the cell — the fixed point of the slot-order loop of engage_kernel), its three patches, its slot's respawn
+//       (every lane that needs one draws its own Philox words: no env-by-env loop); wave 0 alone: reward, env record, outputs
+//                                                                                                                      -> barrier 2
+//   P4  wave 0: the [64, 15] rows; pursuer waves: TE_X_REF and the behaviour tree's command on the post-spawn positions; every wave:
+//       its slot's share of the next flight plan, the persistent-observation record, the patches of auto-reset envs' terminal tiles.
+//
+// Bit for bit what engage_kernel<2, 9> writes (tests/test_gpu_engage_slots.py): the same device functions on the same operands in the
+// same order per value.  Serves the level4 family without a snapshot ring (exp02/03/04/05, evaluation) for D <= 16, drone_contact off;
+// selected per te_env by shard size (te_create) or TE_ENGAGE=slots / regs.
+#pragma once
+#include "te_engage.hpp"
+
+namespace te {
+
+constexpr int kSlotWaves = 16;     // waves of a chunk's workgroup = drone slots served (1 024 threads)
+constexpr int kSlotPursuers = 4;   // pursuers served (the exp tasks have 2)
+constexpr int kSlotsMaxEnvs = 32768;   // te_create's default: shards up to this size take the slot waves (profiles/r04_*_engage_slots*.txt)
+
+struct SlotRows {  // LDS rows of 64 words
+  int D, P;
+  // accumulator rows, zeroed before barrier 0 and OR-ed into by every wave (bit s = slot s): no D-long gather loops afterwards
+  TE_DEV int accS() const { return 0; }      // armed & valid
+  TE_DEV int accZone() const { return 1; }   // armed and outside the dome
+  TE_DEV int accOrg() const { return 2; }    // armed and inside the origin range
+  TE_DEV int accOwn() const { return 3; }    // owns its LIDAR cell (terminal envs alike)
+  TE_DEV int pos(int k, int s) const { return 4 + k * D + s; }        // IMU position as loaded
+  TE_DEV int cellr(int s) const { return 4 + 3 * D + 2 * s; }         // two rows per slot: lane's {cell, range} as one 8-byte word
+  TE_DEV int npos(int k, int s) const { return 4 + (5 + k) * D + s; } // position after the spawn
+  TE_DEV int prec(int q) const { return 4 + 8 * D + q; }              // pursuer record: target + 1 | HIT | EXPLODE | SUICIDE
+};
+__host__ __device__ inline int slot_lds_rows(int D, int P) { return 4 + 8 * D + P; }
+enum : uint32_t { SLOT_HIT = 1u << 8, SLOT_EXPLODE = 1u << 9, SLOT_SUICIDE = 1u << 10 };
+
+#define TE_SLOT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#if defined(TE_DEBUG_STAMPS)
+// phase stamps (diagnostic builds only; tools/slots_stamps.py): waves 0 and 1 of every workgroup, idx 0..7 each
+#define TE_WSTAMP(idx, wait)                                                                                              \
+  do {                                                                                                                    \
+    if (wait) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+    if (p.dbg && s < 2 && lane == 0) p.dbg[64 + blockIdx.x * 16 + s * 8 + (idx)] = __builtin_amdgcn_s_memrealtime();     \
+  } while (0)
+#else
+#define TE_WSTAMP(idx, wait) do {} while (0)
+#endif
+
+template <int DM>
+__global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+  TE_EXACT
+  extern __shared__ uint32_t sm[];
+  const te_config& c = p.cfg;
+  const int D = p.D, P = c.n_pursuers;
+  const SlotRows R{D, P};
+  const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave's drone slot
+  const int env = blockIdx.x * 64 + lane;
+  const bool valid = env < p.N;
+  const GView g{p.dstate, p.estate, D, p.Npad, env, P};
+  const EnvIO io(p, env);
+  const uint32_t pur_bits = (1u << P) - 1u, all_bits = (1u << D) - 1u, inv_bits = all_bits & ~pur_bits;
+  const bool scripted = all_scripted(c);
+  const bool is_p = s < P;
+  auto L = [&](int row) -> uint32_t& { return sm[row * 64 + lane]; };
+  auto Lf = [&](int row) { return __uint_as_float(sm[row * 64 + lane]); };
+  auto Lor = [&](int row, uint32_t v) { __hip_atomic_fetch_or(&sm[row * 64 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  TE_WSTAMP(0, 0);
+
+  // ---- P0: one round of independent loads, all requested before anything is looked at ----------------------------------------------------
+  const uint32_t* __restrict__ lm32 = reinterpret_cast<const uint32_t*>(p.live_mask);
+  const uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane(lm32[2 * blockIdx.x]) & all_bits;   // D <= 16
+  const bool mine_live = is_p || ((live >> s) & 1u);
+  // (a slot nobody of the chunk has armed is requested all the same: a conditional request makes the compiler wait for it inside the branch,
+  // in front of every later request; its lanes are masked below)
+  float mx = io.ldf(TE_D_OBS_POS, s), my = io.ldf(TE_D_OBS_POS + 1, s), mz = io.ldf(TE_D_OBS_POS + 2, s);
+  const uint32_t marmed_w = io.ld(TE_D_ARMED, s);
+  const V3 apos{io.ldf(TE_D_OBS_POS, 0), io.ldf(TE_D_OBS_POS + 1, 0), io.ldf(TE_D_OBS_POS + 2, 0)};
+  float ag[9];  // OBS_EULER, OBS_VEL, OBS_RATE of the agent (wave 0 needs all nine, the others the attitude)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ag[k] = io.ldf(TE_D_OBS_EULER + k, 0);
+#pragma unroll
+  for (int k = 3; k < 9; ++k) ag[k] = 0.0f;
+  const uint32_t w_step = io.le(TE_E_STEP), w_max_step = io.le(TE_E_MAX_STEP), w_round = io.le(TE_E_ROUND), w_episode = io.le(TE_E_EPISODE);
+  // wave 0: the rest of the env record and the action
+  uint32_t w_last_dist = 0u, w_ak = 0u, w_lk = 0u, w_dd = 0u;
+  float4 act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (s == 0) {
+#pragma unroll
+    for (int k = 3; k < 9; ++k) ag[k] = io.ldf(TE_D_OBS_EULER + k, 0);
+    w_last_dist = io.le(TE_E_LAST_DIST); w_ak = io.le(TE_E_AGENT_KILLS); w_lk = io.le(TE_E_ALLIES_KILLS); w_dd = io.le(TE_E_DEADS);
+    if (valid) act = reinterpret_cast<const float4*>(actions)[env];
+  }
+  // pursuer waves: gun, formation point, and every live invader's row
+  uint32_t w_mun = 0u, w_lf = 0u; float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+  float qx[DM], qy[DM], qz[DM]; uint32_t qa[DM];
+#pragma unroll
+  for (int j = 0; j < DM; ++j) { qx[j] = qy[j] = qz[j] = 0.0f; qa[j] = 0u; }
+  if (is_p) {
+    w_mun = io.ld(TE_D_MUNITION, s); w_lf = io.ld(TE_D_LAST_FIRED, s);
+    fx = io.ldf(TE_D_FORMATION, s); fy = io.ldf(TE_D_FORMATION + 1, s); fz = io.ldf(TE_D_FORMATION + 2, s);
+#pragma unroll
+    for (int j = 1; j < DM; ++j) {
+      if ((live >> j) & ~pur_bits >> j & 1u) {
+        qx[j] = io.ldf(TE_D_OBS_POS, j); qy[j] = io.ldf(TE_D_OBS_POS + 1, j); qz[j] = io.ldf(TE_D_OBS_POS + 2, j); qa[j] = io.ld(TE_D_ARMED, j);
+      }
+    }
+  }
+  // an opaque zero, defined HERE: a comparison against it cannot be scheduled in front of this line.  (Comparing a requested word with the
+  // literal 0 lets the compiler sink the test, and the wait for the word, into the branch that requested it: every live invader's row then
+  // cost its own memory round trip, 1.9 us of targeting per pursuer wave.)
+  uint32_t zero = 0u;
+  asm volatile("" : "+s"(zero));
+  if (s == 0) { L(R.accS()) = 0u; L(R.accZone()) = 0u; L(R.accOrg()) = 0u; L(R.accOwn()) = 0u; }
+  TE_SLOT_BARRIER();   // barrier 0: the accumulator rows are zero
+  int step = (int)w_step + 1;  // AGENT_STEP_BROADCAST (exp03_vFinal_environment.py:177-182)
+  int max_step = (int)w_max_step, round = (int)w_round;
+  uint32_t episode = w_episode;
+  int mun = (int)w_mun, lf = (int)w_lf;
+  const float last_dist = __uint_as_float(w_last_dist);
+  int agent_kills = (int)w_ak, allies_kills = (int)w_lk, deads = (int)w_dd;
+  if (!mine_live) { mx = my = mz = 0.0f; }
+  TE_WSTAMP(1, 1);
+
+  // ---- P1: own slot: flags, LIDAR cell in the agent's frame (fused_lidar.py:143-217, lidar_math.py:53-83,262-311) ------------------------
+  const uint32_t a_me = (mine_live && marmed_w != zero && valid) ? 1u : 0u;
+  {
+    const float n = fnorm(V3{mx, my, mz});
+    Lor(R.accS(), a_me << s); Lor(R.accZone(), (a_me & (n > c.dome_radius ? 1u : 0u)) << s); Lor(R.accOrg(), (a_me & (n < c.origin_range ? 1u : 0u)) << s);
+    L(R.pos(0, s)) = __float_as_uint(mx); L(R.pos(1, s)) = __float_as_uint(my); L(R.pos(2, s)) = __float_as_uint(mz);
+  }
+  int cj = 0; float rh = 1.0f;
+  if (s >= 1) {
+    const M3 Rm = x_inverse_attitude(ag[0], ag[1], ag[2]);
+    lidar_cell_fast(c, x_mul(Rm, sub(V3{mx, my, mz}, apos)), cj, rh);
+    *reinterpret_cast<uint2*>(&sm[R.cellr(s) * 64 + 2 * lane]) = make_uint2((uint32_t)cj, __float_as_uint(rh));
+  }
+  // ---- pursuer wave: identify_closest_invader (offsets_handler.py:256-281), process_shoot_range_invaders /
+  // process_explosion_range_invaders (exp03_vFinal_task.py:359-413) for ITS pursuer: none of it depends on another pursuer's outcome
+  if (is_p) {
+    int tgt = -1; float dmin = 0.0f;
+#pragma unroll
+    for (int j = 1; j < DM; ++j) {   // strict '<' in slot order
+      const float d = fdist(V3{mx, my, mz}, V3{qx[j], qy[j], qz[j]});
+      const bool take = a_me != 0u && qa[j] != zero && (tgt < 0 || d < dmin);   // (qa is zero for pursuers, dead slots and slots >= D)
+      tgt = take ? j : tgt;
+      dmin = take ? d : dmin;
+    }
+    uint32_t rec = (uint32_t)(tgt + 1);
+    if (a_me && tgt >= 0 && dmin < c.shoot_range && gun_available(c, mun, lf, step) && mun > 0) {
+      mun -= 1; lf = step;
+      io.st(TE_D_MUNITION, s, (uint32_t)mun); io.st(TE_D_LAST_FIRED, s, (uint32_t)step);
+      const U4 r = env_rng(c, env, RNG_HIT, (uint32_t)s, 0, episode, (uint32_t)step);
+      if (u01(r.x) < c.hit_prob) {  // gun.py:94; entities_manager.shoot_by_ids (:238-248)
+        rec |= SLOT_HIT;
+        if (c.evaluation) g.si(TE_D_KILLS, s, g.gi(TE_D_KILLS, s) + 1);  // lw_kills (evaluation_task.py:498-499)
+      }
+    }
+    if (a_me && tgt >= 0 && dmin < c.explosion_range) rec |= SLOT_EXPLODE | (mun == 0 ? SLOT_SUICIDE : 0u);
+    L(R.prec(s)) = rec;
+  }
+  TE_WSTAMP(2, 0);
+  TE_SLOT_BARRIER();
+  TE_WSTAMP(3, 0);
+
+  // ---- P3: the engagement, by every wave ----------------------------------------------------------------------------------
+  const uint32_t S = L(R.accS()), zone = L(R.accZone()), org = L(R.accOrg());
+  uint32_t killed = 0u;
+  int agent_shots = 0, ally_shots = 0, exploded = 0, pursuer_suicided = 0, agent_suicided = 0;
+  for (int q = 0; q < P; ++q) {
+    const uint32_t r = L(R.prec(q));
+    const int t = (int)(r & 0xFFu) - 1;
+    if (r & SLOT_HIT) { killed |= 1u << t; if (q == 0) agent_shots += 1; else ally_shots += 1; }
+    if (r & SLOT_EXPLODE) {
+      killed |= (1u << q) | (1u << t);
+      if ((r & SLOT_SUICIDE) && q == 0) agent_suicided += 1;
+      else if (r & SLOT_SUICIDE) pursuer_suicided += 1;
+      else exploded += 1;
+    }
+  }
+  // process_invaders_in_origin (:656-659); commented out in Evaluation_Task.on_step_middle (evaluation_task.py:397)
+  if ((!c.evaluation || (c.evaluation & TE_EVAL_ORIGIN_RULE)) && valid) killed |= org & inv_bits;
+  const uint32_t A = S & ~killed;
+  if ((killed >> s) & 1u) io.disarm(s);   // Quadcopter.disarm (quadcopter.py:461-478) of this wave's drone
+  // increment_max_step (:150-153), compute_termination (:517-569)
+  if (agent_shots + ally_shots > 0) max_step += c.step_increment;
+  const int armed_invaders = __popc(A & inv_bits), armed_pursuers = __popc(A & pur_bits);
+  const bool all_rounds_over = armed_invaders == 0 && round >= c.n_rounds;
+  bool term;
+  if (c.evaluation) term = (c.max_step > 0 && step > max_step) || all_rounds_over || zone != 0u || armed_pursuers == 0;
+  else term = step > max_step || all_rounds_over || zone != 0u || armed_pursuers == 0 || (c.agent_death_terminates && !(A & 1u)) || apos.z < -5.99f;
+  const bool to_terminal = valid && term && c.auto_reset;
+  // ---- closer wins (lidar_math.py:262-311): the slot-order loop ends with, in every cell, the armed drone of smallest (range, slot);
+  // a drone at range 1.0 never owns a cell (an empty cell holds 1.0).  Only slots some env of the chunk has armed can contest a cell.
+  bool own = false;
+  if (s >= 1) {
+    own = ((A >> s) & 1u) != 0u && rh < 1.0f;
+    for (uint32_t m = live & ~1u & ~(1u << s); m; m &= m - 1u) {
+      const int k = __ffs((int)m) - 1;
+      const uint2 cr = *reinterpret_cast<const uint2*>(&sm[R.cellr(k) * 64 + 2 * lane]);
+      const float rk = __uint_as_float(cr.y);
+      const bool beaten = ((A >> k) & 1u) != 0u && cr.x == (uint32_t)cj && (rk < rh || (rk == rh && k < s));
+      own = own && !beaten;
+    }
+    if (own && valid) Lor(R.accOwn(), 1u << s);
+  }
+  const float flag_me = (float)(s < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;   // lidar_math.py:305
+  const bool time_plane = c.lidar_channels != 2;
+  auto patch = [&](float* dst) {   // time plane = Delta 1 of a 10-deep ring (perception_snapshot.py:36-37)
+    dst += (size_t)env * lidar_words(c);
+    dst[cj] = rh; dst[TE_LIDAR_CELLS + cj] = flag_me;
+    if (time_plane) dst[2 * TE_LIDAR_CELLS + cj] = 0.1f;
+  };
+  if (valid && own && !to_terminal && o.obs.lidar) patch(o.obs.lidar);
+  // terminal tiles: ones, every wave its share; acknowledged before barrier 2, behind which the owners patch them
+  const unsigned long long term_b = __ballot(to_terminal);
+  if (o.term.lidar && term_b) {
+    for (unsigned long long tb = term_b; tb; tb &= tb - 1) {
+      const int l = __ffsll((long long)tb) - 1;
+      float* tile = o.term.lidar + (size_t)(blockIdx.x * 64 + l) * lidar_words(c);
+      for (int e = s * 64 + lane; e < lidar_words(c); e += 64 * D) tile[e] = 1.0f;
+    }
+  }
+
+  // ---- wave 0: reward, env record, outputs (exp03_vFinal_task.py:423-578) ----------------------------------------------------
+  auto pos_of = [&](int t) { return V3{__uint_as_float(sm[R.pos(0, t) * 64 + lane]), __uint_as_float(sm[R.pos(1, t) * 64 + lane]), __uint_as_float(sm[R.pos(2, t) * 64 + lane])}; };
+  if (s == 0) {
+    if (valid) {
+      io.stef(TE_E_LAST_ACTION + 0, act.x); io.stef(TE_E_LAST_ACTION + 1, act.y); io.stef(TE_E_LAST_ACTION + 2, act.z); io.stef(TE_E_LAST_ACTION + 3, act.w);
+      io.ste(TE_E_STEP, (uint32_t)step);
+      io.ste(TE_E_SNAP_MASK, S); io.ste(TE_E_SNAP_MASK_HI, 0u);
+    }
+    agent_kills += agent_shots; allies_kills += ally_shots; deads += exploded;
+    if (to_terminal) {
+      if (o.term.inertial) inertial_row_regs(c, o.term.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, mx, my, mz, ag, mun, lf, step);
+      if (o.term.last_action) reinterpret_cast<float4*>(o.term.last_action)[env] = act;
+    }
+    float reward = 0.0f, cur_dist = last_dist;
+    if (!c.evaluation) {
+      float gs[3];
+      gun_state(c, mun, lf, step, max_munition_of(c, 0), gs);
+      const float dist_origin = fnorm(apos);
+      int ally = -1;  // identify_closest_ally (offsets_handler.py:167-190)
+      if ((S & 1u) && __popc(S & pur_bits) > 1) {
+        float bd = 0.0f;
+        for (int a = 1; a < P; ++a) {
+          if ((S >> a) & 1u) {
+            const float d = fdist(pos_of(a), apos);
+            if (ally < 0 || d < bd) { ally = a; bd = d; }
+          }
+        }
+      }
+      const int chooser = ally < 0 ? 0 : ally;   // the reward's target: the closest invader of the agent's closest ally, or of the agent alone
+      const int target = ((S >> chooser) & 1u) ? (int)(sm[R.prec(chooser) * 64 + lane] & 0xFFu) - 1 : -1;
+      const V3 tp = target >= 0 ? pos_of(target) : V3{0.0f, 0.0f, 0.0f};
+      cur_dist = fdist(apos, tp);
+      const bool ready = gs[2] == 1.0f || gs[0] == 0.0f;
+      float bonus = 0.0f, penalty = 0.0f;
+      if (0.01f < last_dist - cur_dist && ready) bonus += c.approach_bonus_gain * fnorm(V3{ag[3], ag[4], ag[5]});
+      const float score = ready ? -cur_dist : cur_dist * (2.0f * gs[1] - 1.0f);
+      if (agent_shots > 0 || agent_suicided > 0) bonus += (float)(agent_shots + agent_suicided) * 1000.0f;
+      if (ally_shots > 0 || pursuer_suicided > 0) bonus += 0.5f * (float)(ally_shots + pursuer_suicided) * 1000.0f;
+      else if (exploded > 0) penalty += 1000.0f * (float)exploded;
+      if (apos.z < -5.0f) penalty += (-5.0f - apos.z) * 1000.0f;
+      if (zone & pur_bits) penalty += 1000.0f;
+      if (dist_origin > c.born_radius - 2.0f) penalty += dist_origin - c.born_radius - 2.0f;  // literal
+      reward = score + bonus - penalty;
+    }
+    if (valid) {
+      if (!c.evaluation) io.stef(TE_E_LAST_DIST, cur_dist);
+      io.ste(TE_E_AGENT_KILLS, (uint32_t)agent_kills); io.ste(TE_E_ALLIES_KILLS, (uint32_t)allies_kills); io.ste(TE_E_DEADS, (uint32_t)deads);
+      if (agent_shots + ally_shots > 0) io.ste(TE_E_MAX_STEP, (uint32_t)max_step);
+      o.reward[env] = reward;
+      o.done[env] = term ? 1 : 0;
+      reinterpret_cast<int4*>(o.info)[env] = make_int4(agent_kills, allies_kills, deads, round);
+      io.ste(TE_E_INFO_WAVE, (uint32_t)round);   // (on_step_end below may start the next wave; an auto-reset puts 1 back)
+    }
+  }
+
+  // ---- on_step_end (:321-333): next wave when this one is cleared and a pursuer is alive; SB3 auto-reset (every wave decides, wave 0 stores)
+  uint32_t task = 0u;   // round | reset << 8: the slots of this env have to be respawned
+  uint32_t snap_mask = S;
+  auto mask_after_spawn = [&](int rnd, bool reset) {
+    const uint32_t m = reset ? pur_bits : (A & pur_bits);
+    const int n = invaders_in_round(c, rnd);
+    return (uint32_t)(m | ((((1u << n) - 1u) << P) & all_bits));
+  };
+  if (valid && !term && armed_invaders == 0 && armed_pursuers > 0) {
+    round = round + (round < c.n_rounds ? 1 : c.n_rounds);  // advance_round (:155-175)
+    snap_mask = mask_after_spawn(round, false);
+    if (s == 0) { io.ste(TE_E_ROUND, (uint32_t)round); io.ste(TE_E_SNAP_MASK, snap_mask); io.ste(TE_E_SNAP_MASK_HI, 0u); }
+    task = (uint32_t)round;
+  }
+  if (to_terminal) {  // Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146): the env record by wave 0, every slot by its wave
+    episode += 1u; step = 0; max_step = c.max_step; round = 1;
+    snap_mask = mask_after_spawn(1, true);
+    if (s == 0) {
+      io.ste(TE_E_EPISODE, episode); io.ste(TE_E_STEP, 0u); io.ste(TE_E_MAX_STEP, (uint32_t)c.max_step); io.ste(TE_E_ROUND, 1u); io.ste(TE_E_INFO_WAVE, 1u);
+      io.ste(TE_E_AGENT_KILLS, 0u); io.ste(TE_E_ALLIES_KILLS, 0u); io.ste(TE_E_DEADS, 0u);
+      if (c.reward_model != TE_REWARD_L5_C1) io.stef(TE_E_LAST_DIST, c.dome_radius);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) io.ste(TE_E_LAST_ACTION + k, 0u);
+      io.ste(TE_E_SNAP_MASK, snap_mask); io.ste(TE_E_SNAP_MASK_HI, 0u);
+    }
+    act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ag[k] = 0.0f;
+    task = 1u | (1u << 8);
+  }
+  // ---- spawn of this wave's slot: every lane whose env starts a round or resets draws its own position (Task.setup_round / on_reset)
+  if (task != 0u) {
+    const bool reset = (task >> 8) != 0u;
+    V3 w{0.0f, 0.0f, 0.0f};
+    const bool placed = spawn_slot_at(c, g, s, (int)(task & 0xFFu), episode, reset, ((A >> s) & 1u) != 0u, w);
+    if (placed) { mx = w.x; my = w.y; mz = w.z; }
+    if (reset && is_p) { mun = max_munition_of(c, s); lf = -c.cooldown_steps; fx = mx; fy = my; fz = mz; }
+  }
+  const uint32_t armed_post = task != 0u ? snap_mask : A;   // after the spawn: the pursuers as they are (all armed on reset) + the round's invaders
+  L(R.npos(0, s)) = __float_as_uint(mx); L(R.npos(1, s)) = __float_as_uint(my); L(R.npos(2, s)) = __float_as_uint(mz);
+  if (o.term.lidar && term_b) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the terminal tiles has landed
+  TE_WSTAMP(4, 0);
+  TE_SLOT_BARRIER();
+  TE_WSTAMP(5, 0);
+
+  // ---- P4 ---------------------------------------------------------------------------------------------------------------------
+  if (s >= 1 && to_terminal && own && o.term.lidar) patch(o.term.lidar);
+  if (o.persist && o.obs.lidar && valid) {   // persistent observation: which cells of the MAIN buffer hold a feature now, in slot order
+    const uint32_t owners = L(R.accOwn());
+    uint16_t* pv = o.prev + env;
+    if (s == 0) pv[0] = (uint16_t)(to_terminal ? 0 : __popc(owners));
+    else if (own && !to_terminal) pv[(size_t)(__popc(owners & ((1u << s) - 1u)) + 1) * p.Npad] = (uint16_t)cj;
+  }
+  if (s == 0) {   // the observation of the state the step leaves (post-reset values for an auto-reset env): 15 words per lane, 60 contiguous bytes
+    if (o.obs.inertial && valid) inertial_row_regs(c, o.obs.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, mx, my, mz, ag, mun, lf, step);
+    if (valid && o.obs.last_action) reinterpret_cast<float4*>(o.obs.last_action)[env] = act;
+  }
+  // ---- pursuer waves: the position the invaders steer at during the next sub-step launch (TE_X_REF), the scripted ally's command of the
+  // next step (Task.on_step_start -> LoyalWingmanBehaviorTree.update, loyalwingman_navigator.py:238-352)
+  if (is_p && valid) {
+    int first_skipped = -1;  // drive_loyalwingmen: get_armed_pursuers()[1:] — with the agent dead the first armed ally is skipped
+    if (!scripted && !(armed_post & 1u)) first_skipped = (armed_post & pur_bits & ~1u) ? __ffs((int)(armed_post & pur_bits & ~1u)) - 1 : -1;
+    io.stf(TE_X_REF + 0, s, mx); io.stf(TE_X_REF + 1, s, my); io.stf(TE_X_REF + 2, s, mz);
+    if ((s > 0 || scripted) && ((armed_post >> s) & 1u) && s != first_skipped) {
+      float out[3] = {0.0f, 0.0f, 0.0f};
+      const bool ext = driven_externally(c, s);
+      if (!ext && c.ally_policy == TE_ALLY_BT) {
+        const V3 me{mx, my, mz};
+        if (gun_available(c, mun, lf, step)) {
+          int t = -1; float bd = 0.0f; V3 tp{0.0f, 0.0f, 0.0f};
+          if ((snap_mask >> s) & 1u) {
+            for (int j = P; j < D; ++j) {
+              if (__ballot((snap_mask >> j) & 1u) == 0ull) continue;   // nobody of the chunk has slot j armed: its row is not read
+              if ((snap_mask >> j) & 1u) {
+                const V3 pj{Lf(R.npos(0, j)), Lf(R.npos(1, j)), Lf(R.npos(2, j))};
+                const float d = fdist(me, pj);
+                if (t < 0 || d < bd) { t = j; bd = d; tp = pj; }
+              }
+            }
+          }
+          x_cmd_toward(me, tp, c.ally_speed, out);
+        } else x_cmd_toward(me, V3{fx, fy, fz}, c.ally_speed, out);
+      } else if (ext || c.ally_policy != TE_ALLY_FROZEN) {  // nobody / the caller's policy: the set-point persists
+        out[0] = g.gf(TE_D_SETPOINT + 0, s); out[1] = g.gf(TE_D_SETPOINT + 1, s); out[2] = g.gf(TE_D_SETPOINT + 3, s);
+      }
+      io.stf(TE_X_CMD + 0, s, out[0]); io.stf(TE_X_CMD + 1, s, out[1]); io.stf(TE_X_CMD + 2, s, out[2]);
+    }
+  }
+  // ---- what the next sub-step launch has to fly for this chunk (post-spawn flags): a wave walks the slots up to its own and writes its
+  // items; the last wave has walked them all and writes the chunk's masks
+  if (s >= 1) {
+    uint64_t dense = 0u, livem = 0u; int n = 0;
+    uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
+    for (int k = 0; k <= s; ++k) {
+      const bool a = valid && ((armed_post >> k) & 1u) != 0u;
+      const unsigned long long b = __ballot(a);
+      const int cnt = __popcll(b);
+      if (cnt == 0) continue;
+      livem |= (uint64_t)1 << k;
+      if (k == 0 || cnt >= p.dense_min || n + cnt > kMixedCap) { dense |= (uint64_t)1 << k; continue; }
+      if (k == s && a) items[n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | (k << 8));
+      n += cnt;
+    }
+    if (s == D - 1 && lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = (uint32_t)n; p.live_mask[blockIdx.x] = livem; }
+  }
+  TE_WSTAMP(6, 0);
+  TE_WSTAMP(7, 1);
+}
+
+}  // namespace te

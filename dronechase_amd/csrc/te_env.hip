@@ -35,6 +35,7 @@
 #include "te_stacked.hpp"
 #include "te_stackview.hpp"
 #include "te_engage.hpp"
+#include "te_engage_slots.hpp"
 
 namespace te {
 
@@ -835,6 +836,7 @@ struct te_env {
   size_t dbg_words = 0;       // diagnostic builds: length of p.dbg
   int engage_regs = 0;         // 1 = engage_kernel<2, 9>, 2 = engage_kernel<6, 12> (level4 family), 3 = engage_stage02_kernel<2, 8>, 4 = engage_stage01_kernel (te_engage.hpp: the env in registers, one wave per
                                // chunk); 0 = engage_observe_kernel (LDS phases): other shapes, stage01 / stage02, TE_ENGAGE=lds
+  int engage_slots = 0;        // 1 = engage_slots_kernel (te_engage_slots.hpp: one wave per (chunk, slot)) instead of engage_kernel: small shards, TE_ENGAGE=slots
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
   float* zero_actions = nullptr;     // te_step_students: the [N,4] action batch nobody reads (every pursuer is scripted)
   uint32_t* ally_scratch = nullptr;  // te_observe_wingman: owner planes between its two launches (te_create allocates them when a wingman is caller-driven)
@@ -987,6 +989,12 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   } else if (e->family == FAM_STAGE01) e->engage_regs = 4;
   if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "lds")) e->engage_regs = 0; }
   const bool regs_l4 = e->engage_regs == 1 || e->engage_regs == 2 || e->engage_regs == 5;
+  // one wave per (chunk, slot) instead of one wave per chunk: a shard with fewer chunks than the chip has SIMDs is one dependent chain per
+  // wave, and the chain is what the slot waves shorten (te_engage_slots.hpp); large shards keep engage_kernel (fewer instructions in total)
+  if (regs_l4 && !cfg->stacked_obs && D <= kSlotWaves && cfg->n_pursuers <= kSlotPursuers && cfg->reward_model == TE_REWARD_EXP03 && !cfg->drone_contact) {
+    e->engage_slots = cfg->n_envs <= kSlotsMaxEnvs ? 1 : 0;
+    if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "slots")) e->engage_slots = 1; else if (!strcmp(v, "regs")) e->engage_slots = 0; }
+  }
   if (D > kMaxD && !(regs_l4 && cfg->stacked_obs))
     return bail("te_create: more than 32 drones per env are served for the stacked-observation tasks only (te_step_stacked / te_step_students: stacked_obs, P <= 7, P + I <= 37)");
   if ((cfg->agent_scripted || cfg->reward_model != TE_REWARD_EXP03 || !cfg->agent_death_terminates || cfg->initial_invaders != 1 || cfg->invaders_per_round != 1) && !regs_l4)
@@ -1294,7 +1302,8 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   StepOut o{reward, done, info, ObsOut{stack ? nullptr : obs_lidar, obs_inertial, obs_last_action},
             ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}, e->prev_cells, stack ? 0 : persist};
   const bool contact = p.cfg.drone_contact != 0;   // its own instantiations: the contact pass would cost every launch ~150 VGPRs
-  if (e->engage_regs == 1 && !contact) TE_LAUNCH((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, p, actions, o);
+  if (e->engage_slots && !contact) TE_LAUNCH((engage_slots_kernel<kSlotWaves>), dim3(b2), dim3(64 * p.D), (size_t)slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
+  else if (e->engage_regs == 1 && !contact) TE_LAUNCH((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, p, actions, o);
   else if (e->engage_regs == 2 && !contact) TE_LAUNCH((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, p, actions, o);
 #ifndef TE_DEBUG_STAMPS  // the stamp build leaves the contact variants out (the compiler rejects them next to the stamp stores)
   else if (e->engage_regs == 1) TE_LAUNCH((engage_kernel<2, 9, true>), dim3(b2), dim3(64), 0, p, actions, o);

@@ -175,6 +175,7 @@ template <class V> TE_DEV uint32_t armed_mask(const V& v) {
 // Cephes sinf / cosf minimax polynomials, < 1 ulp of the result's scale.  libm's sincosf carries its large-argument reduction along:
 // a respawning wave of the engage kernel paid ~0.3 us per call on its critical path (it is the kernel's slowest wave).
 TE_DEV void sincos_0_pi(float x, float& s, float& c) {
+  TE_EXACT   // (inlined into several kernels whose spawns are compared bitwise: te_device.hpp "exact arithmetic")
   const int q = x < 0.7853981633974483f ? 0 : (x < 2.356194490192345f ? 1 : 2);   // nearest multiple of pi/2
   const float y = (float)q * 2.0f;                                              // in units of pi/4
   const float r = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
@@ -185,9 +186,10 @@ TE_DEV void sincos_0_pi(float x, float& s, float& c) {
   c = q == 0 ? cr : (q == 1 ? -sr : -cr);
 }
 TE_DEV V3 level4_position(const te_config& c, float r, float u_theta, float u_phi) {
+  TE_EXACT
   float theta = u_theta * kPi;
   float lower = fminf(c.born_min_z, r);
-  float min_phi = 0.5f * kPi - fast_asin(lower * rcp(r));   // acos on the polynomial asin of the sub-step loop (1e-7 abs)
+  float min_phi = 0.5f * kPi - x_asin(lower * rcp(r));   // acos on the polynomial asin of the sub-step loop (1e-7 abs)
   float phi = (r >= c.born_min_z) ? min_phi + u_phi * (0.5f * kPi - min_phi) : u_phi * (0.5f * kPi);
   float sph, cph, sth, cth;
   sincos_0_pi(phi, sph, cph); sincos_0_pi(theta, sth, cth);

@@ -1,0 +1,108 @@
+"""engage_slots_kernel (te_engage_slots.hpp: one wave per (chunk, drone slot), a workgroup per chunk; the small-shard form of the
+engage/observe step) must write bit for bit what engage_kernel<2, 9> (one lane per env, one wave per chunk) writes: every output of every
+step, the terminal buffers of the done envs, and the whole state blob, along free-running rollouts with auto-resets, wave advances, shots,
+explosions, ragged N, the persistent observation, and the task switches of the level4 family.  TE_ENGAGE=slots / regs selects the kernel
+when the te_env is created."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(monkeypatch, task, n, **over):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    envs = []
+    for mode in ("slots", "regs"):
+        monkeypatch.setenv("TE_ENGAGE", mode)
+        envs.append(BatchedEnv(default_config(task, n_envs=n, **over), "cuda:0"))
+    monkeypatch.delenv("TE_ENGAGE")
+    return envs
+
+
+def _same_rollout(a, b, steps, seed=11, persistent=False, external=False):
+    import torch
+    if persistent:
+        a.set_persistent_obs(True); b.set_persistent_obs(True)
+    ra, rb = a.reset(), b.reset()
+    for x, y in zip(ra, rb):
+        assert torch.equal(x, y)
+    n_done = 0
+    for s in range(steps):
+        act = a.random_actions(seed, s)
+        if external:
+            for e in (a, b):
+                e.observe_ally(); e.set_ally_actions(a.random_actions(seed + 1000, s))
+        oa, ob = a.step(act, terminal=True), b.step(act, terminal=True)
+        for k, (x, y) in enumerate(zip(oa, ob)):
+            assert torch.equal(x, y), f"output {k} differs at step {s}"
+        d = oa[4].bool()
+        n_done += int(d.sum().item())
+        if d.any():
+            for name in ("t_lidar", "t_inertial", "t_last_action"):
+                assert torch.equal(getattr(a, name)[d], getattr(b, name)[d]), f"{name} differs at step {s}"
+        if s % 8 == 7 or s == steps - 1:
+            assert torch.equal(a.get_state(), b.get_state()), f"state differs after step {s}"
+    return n_done
+
+
+@pytest.mark.parametrize("task,n,over", [
+    ("stage03", 8192, {}), ("stage03", 1000, {"seed": 5}), ("exp02", 4096, {}), ("exp04", 2048, {}), ("evaluation", 2048, {}),
+    ("stage03", 2048, {"lidar_channels": 2}), ("stage03", 2048, {"motor_noise": 0, "quad_preset": 0}),
+])
+def test_slot_waves_equal_the_one_wave_kernel_along_rollouts(monkeypatch, task, n, over):
+    a, b = _pair(monkeypatch, task, n, **over)
+    n_done = _same_rollout(a, b, 200)
+    assert n_done > 0 or n < 4096 or task == "evaluation"
+    a.close(); b.close()
+
+
+def test_slot_waves_with_short_episodes_and_the_persistent_observation(monkeypatch):
+    """max_step = 9: every env auto-resets every ten steps (terminal tiles, respawns of every slot, the reset observation), next to wave
+    advances; then the same with the own sphere updated in place."""
+    for persistent in (False, True):
+        a, b = _pair(monkeypatch, "stage03", 3000, seed=2, max_step=9)
+        assert _same_rollout(a, b, 60, persistent=persistent) > 10000
+        a.close(); b.close()
+
+
+def test_slot_waves_with_a_caller_driven_ally(monkeypatch):
+    a, b = _pair(monkeypatch, "exp05", 2048)
+    _same_rollout(a, b, 120, external=True)
+    a.close(); b.close()
+
+
+def test_slot_waves_on_the_all_armed_state(monkeypatch):
+    """Every slot armed (round 9), invaders on the born sphere: shots, explosions and double credits within a few steps, eleven live waves per chunk."""
+    import torch
+    from dronechase_amd import config as K
+    a, b = _pair(monkeypatch, "stage03", 4096, seed=8)
+    a.reset(); b.reset()
+    w = a.get_state().clone()
+    N, D = 4096, 11
+    dr = w[: N * D * K.DRONE_WORDS].view(N, D, K.DRONE_WORDS)
+    er = w[N * D * K.DRONE_WORDS: N * (D * K.DRONE_WORDS + K.ENV_WORDS)].view(N, K.ENV_WORDS)
+    g = torch.Generator(device="cuda:0"); g.manual_seed(4)
+    dead = dr[:, :, K.D["ARMED"]] == 0
+    # close to the pursuers (who start at r = 2): within shooting range of some, within explosion range of a few
+    pos3 = (torch.rand((N, D, 3), device="cuda:0", generator=g) - 0.5) * 3.0 + torch.tensor([0.0, 1.0, 1.0], device="cuda:0")
+    fl = dr.view(torch.float32)
+    for k in range(3):
+        fl[:, :, K.D["POS"] + k] = torch.where(dead, pos3[:, :, k], fl[:, :, K.D["POS"] + k])
+        fl[:, :, K.D["OBS_POS"] + k] = torch.where(dead, pos3[:, :, k], fl[:, :, K.D["OBS_POS"] + k])
+    dr[:, :, K.D["ARMED"]] = 1
+    er[:, K.E["ROUND"]] = 9
+    er[:, K.E["SNAP_MASK"]] = (1 << D) - 1
+    a.set_state(w); b.set_state(w)
+    kills = 0
+    for s in range(40):
+        act = a.random_actions(3, s)
+        oa, ob = a.step(act, terminal=True), b.step(act, terminal=True)
+        for k, (x, y) in enumerate(zip(oa, ob)):
+            assert torch.equal(x, y), f"output {k} differs at step {s}"
+        kills += int(oa[5][:, 0].sum().item())
+    assert torch.equal(a.get_state(), b.get_state()) and kills > 1000
+    a.close(); b.close()

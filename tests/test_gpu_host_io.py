@@ -92,8 +92,7 @@ def test_persistent_observation_under_host_io_is_bitwise_the_dense_one(task):
     hs = []
     for persistent in (1, 0):
         cfg = default_config(task, n_envs=N, seed=9, io_location=K.IO_HOST)
-        if task == "stage03":
-            cfg.max_step = 12   # episodes end (and auto-reset) every dozen steps: many done rows per step
+        cfg.max_step = 12   # episodes end (and auto-reset) every dozen steps: many done rows per step
         h = C.c_void_p()
         _lib.check(L.te_create(C.byref(cfg), 0, C.byref(h)), "te_create")
         _lib.check(L.te_set_persistent_obs(h, persistent), "te_set_persistent_obs")
@@ -118,6 +117,6 @@ def test_persistent_observation_under_host_io_is_bitwise_the_dense_one(task):
         n_done += int(d.sum())
         for k in ("tl", "ti", "ta"):
             assert np.array_equal(a[k][d], b[k][d]), (s, k)
-    assert n_done > (2000 if task == "stage03" else 0)
+    assert n_done > 2000
     for h in hs:
         L.te_destroy(h)
