@@ -86,17 +86,6 @@ TE_DEV V3 x_mul(const M3& R, V3 v) {
   TE_EXACT
   return V3{xfma(R.m02, v.z, xfma(R.m01, v.y, R.m00 * v.x)), xfma(R.m12, v.z, xfma(R.m11, v.y, R.m10 * v.x)), xfma(R.m22, v.z, xfma(R.m21, v.y, R.m20 * v.x))};
 }
-// cmd_toward (te_logic.hpp) + Quadcopter.convert_command_to_setpoint (te_device.hpp: command_to_velocity): the behaviour tree's command
-TE_DEV void x_cmd_toward(V3 from, V3 to, float speed, float out[3]) {
-  TE_EXACT
-  const float dx = to.x - from.x, dy = to.y - from.y, dz = to.z - from.z;
-  const float n = sqrtf(xfma(dz, dz, xfma(dy, dy, dx * dx)));
-  const float inv = n > 0.0f ? 1.0f / n : 1.0f;  // zero vector stays zero (…air_combat_only.py:191-195)
-  const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
-  const float m = sqrtf(xfma(uz, uz, xfma(uy, uy, ux * ux)));
-  const float inv2 = 1.0f / (m > 0.0f ? m : 1.0f);
-  out[0] = speed * (ux * inv2); out[1] = speed * (uy * inv2); out[2] = speed * (uz * inv2);
-}
 // lidar_cell (te_logic.hpp) on the native sqrt / rcp and the polynomial asin / atan2 of the sub-step loop (1e-7 abs): a tenth of
 // libm's acosf + atan2f instructions, which were a third of this kernel's straight-line path
 TE_DEV void lidar_cell_fast(const te_config& c, V3 local, int& cell, float& rhat) {
@@ -795,6 +784,7 @@ TE_DEV void terminal_tiles(const te_config& c, float* t_lidar, bool to_terminal,
 // ---- stage02: L3Stage1.on_step_middle / on_step_end (level3/components/stages.py:144-179,241-344), the restatement of stage02_logic
 template <int PM, int IM>
 __global__ __launch_bounds__(64) void engage_stage02_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+  TE_EXACT   // (the reward is computed by engage_slots_stage02_kernel too: te_device.hpp "exact arithmetic")
   constexpr int DM = PM + IM;
   __shared__ float rows[64 * TE_OBS_INERTIAL_WORDS];
   const te_config& c = p.cfg;

@@ -27,7 +27,10 @@ namespace te {
 
 constexpr int kSlotWaves = 16;     // waves of a chunk's workgroup = drone slots served (1 024 threads)
 constexpr int kSlotPursuers = 4;   // pursuers served (the exp tasks have 2)
-constexpr int kSlotsMaxEnvs = 32768;   // te_create's default: shards up to this size take the slot waves (profiles/r04_*_engage_slots*.txt)
+// te_create's default: shards of up to this many (env, slot) pairs take the slot waves; above it engage_kernel's single wave per chunk issues fewer
+// instructions in total and the chip is full either way (stage03: 18.1 vs 20.4 us at 32 768 envs, 24.6 vs 23.7 at 49 152, 31.0 vs 27.5 at 65 536;
+// exp02, 7 slots: 17.9 vs 19.0 at 65 536; profiles/r04_c_ab_engage_slots.txt)
+constexpr int kSlotsMaxPairs = 460000;
 
 struct SlotRows {  // LDS rows of 64 words
   int D, P;
@@ -40,8 +43,9 @@ struct SlotRows {  // LDS rows of 64 words
   TE_DEV int cellr(int s) const { return 4 + 3 * D + 2 * s; }         // two rows per slot: lane's {cell, range} as one 8-byte word
   TE_DEV int npos(int k, int s) const { return 4 + (5 + k) * D + s; } // position after the spawn
   TE_DEV int prec(int q) const { return 4 + 8 * D + q; }              // pursuer record: target + 1 | HIT | EXPLODE | SUICIDE
+  TE_DEV int prec2(int q) const { return 4 + 8 * D + 2 * q; }         // stage02: two rows per pursuer: lane's {record, distance to the target}
 };
-__host__ __device__ inline int slot_lds_rows(int D, int P) { return 4 + 8 * D + P; }
+__host__ __device__ inline int slot_lds_rows(int D, int P) { return 4 + 8 * D + 2 * P; }
 enum : uint32_t { SLOT_HIT = 1u << 8, SLOT_EXPLODE = 1u << 9, SLOT_SUICIDE = 1u << 10 };
 
 #define TE_SLOT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -394,6 +398,237 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
   }
   TE_WSTAMP(6, 0);
   TE_WSTAMP(7, 1);
+}
+
+// ---- stage02 (L3Stage1.on_step_middle / on_step_end, level3/components/stages.py:144-179,241-344) in the same form: bit for bit what
+// engage_stage02_kernel<2, 8> writes.  Differences from the level4 family: the suicide rule (a pursuer without munition kills by contact at
+// shoot range), every kill counts for the agent, killed invaders come back inside the step, no waves, no behaviour tree.
+enum : uint32_t { SLOT2_KILL = 1u << 8 };   // pursuer record: target + 1 | KILL (shot that hit, or the suicide rule) | SLOT_EXPLODE; its row pair holds dmin too
+
+template <int DM>
+__global__ __launch_bounds__(DM * 64) void engage_slots_stage02_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+  TE_EXACT
+  extern __shared__ uint32_t sm[];
+  const te_config& c = p.cfg;
+  const int D = p.D, P = c.n_pursuers;
+  const SlotRows R{D, P};
+  const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int env = blockIdx.x * 64 + lane;
+  const bool valid = env < p.N;
+  const EnvIO io(p, env);
+  const uint32_t pur_bits = (1u << P) - 1u, all_bits = (1u << D) - 1u, inv_bits = all_bits & ~pur_bits;
+  const bool is_p = s < P;
+  auto L = [&](int row) -> uint32_t& { return sm[row * 64 + lane]; };
+  auto Lf = [&](int row) { return __uint_as_float(sm[row * 64 + lane]); };
+  auto Lor = [&](int row, uint32_t v) { __hip_atomic_fetch_or(&sm[row * 64 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+
+  // ---- P0: loads
+  float mx = io.ldf(TE_D_OBS_POS, s), my = io.ldf(TE_D_OBS_POS + 1, s), mz = io.ldf(TE_D_OBS_POS + 2, s);
+  const uint32_t marmed_w = io.ld(TE_D_ARMED, s);
+  const V3 apos{io.ldf(TE_D_OBS_POS, 0), io.ldf(TE_D_OBS_POS + 1, 0), io.ldf(TE_D_OBS_POS + 2, 0)};
+  float ag[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ag[k] = io.ldf(TE_D_OBS_EULER + k, 0);
+#pragma unroll
+  for (int k = 3; k < 9; ++k) ag[k] = 0.0f;
+  const uint32_t w_step = io.le(TE_E_STEP), w_max_step = io.le(TE_E_MAX_STEP), w_episode = io.le(TE_E_EPISODE);
+  uint32_t w_kills = 0u, w_deads = 0u, w_last = 0u;
+  float4 act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (s == 0) {
+#pragma unroll
+    for (int k = 3; k < 9; ++k) ag[k] = io.ldf(TE_D_OBS_EULER + k, 0);
+    w_kills = io.le(TE_E_AGENT_KILLS); w_deads = io.le(TE_E_DEADS); w_last = io.le(TE_E_PREV_SNAP_MIN);
+    if (valid) act = reinterpret_cast<const float4*>(actions)[env];
+  }
+  uint32_t w_mun = 0u, w_lf = 0u;
+  float qx[DM], qy[DM], qz[DM]; uint32_t qa[DM];
+#pragma unroll
+  for (int j = 0; j < DM; ++j) { qx[j] = qy[j] = qz[j] = 0.0f; qa[j] = 0u; }
+  if (is_p) {
+    w_mun = io.ld(TE_D_MUNITION, s); w_lf = io.ld(TE_D_LAST_FIRED, s);
+#pragma unroll
+    for (int j = 1; j < DM; ++j) {
+      if ((inv_bits >> j) & 1u) {
+        qx[j] = io.ldf(TE_D_OBS_POS, j); qy[j] = io.ldf(TE_D_OBS_POS + 1, j); qz[j] = io.ldf(TE_D_OBS_POS + 2, j); qa[j] = io.ld(TE_D_ARMED, j);
+      }
+    }
+  }
+  uint32_t zero = 0u;   // (see engage_slots_kernel)
+  asm volatile("" : "+s"(zero));
+  if (s == 0) { L(R.accS()) = 0u; L(R.accZone()) = 0u; L(R.accOrg()) = 0u; L(R.accOwn()) = 0u; }
+  TE_SLOT_BARRIER();
+  int step = (int)w_step + 1;
+  const int max_step = (int)w_max_step;
+  uint32_t episode = w_episode;
+  int mun = (int)w_mun, lf = (int)w_lf;
+  int kills = (int)w_kills, deads = (int)w_deads;
+  const float last = __uint_as_float(w_last);
+
+  // ---- P1: own slot
+  const uint32_t a_me = (marmed_w != zero && valid) ? 1u : 0u;
+  {
+    const float n = fnorm(V3{mx, my, mz});
+    Lor(R.accS(), a_me << s); Lor(R.accZone(), (a_me & (n > c.dome_radius ? 1u : 0u)) << s);
+    L(R.pos(0, s)) = __float_as_uint(mx); L(R.pos(1, s)) = __float_as_uint(my); L(R.pos(2, s)) = __float_as_uint(mz);
+  }
+  int cj = 0; float rh = 1.0f;
+  if (s >= 1) {
+    const M3 Rm = x_inverse_attitude(ag[0], ag[1], ag[2]);
+    lidar_cell_fast(c, x_mul(Rm, sub(V3{mx, my, mz}, apos)), cj, rh);
+    *reinterpret_cast<uint2*>(&sm[R.cellr(s) * 64 + 2 * lane]) = make_uint2((uint32_t)cj, __float_as_uint(rh));
+  }
+  if (is_p) {   // closest invader, shoot_by_ids with the suicide rule (level3/components/quadcopter_manager.py:155-171), explosion
+    int tgt = -1; float dmin = 0.0f;
+#pragma unroll
+    for (int j = 1; j < DM; ++j) {
+      const float d = fdist(V3{mx, my, mz}, V3{qx[j], qy[j], qz[j]});
+      const bool take = a_me != 0u && qa[j] != zero && (tgt < 0 || d < dmin);
+      tgt = take ? j : tgt; dmin = take ? d : dmin;
+    }
+    uint32_t rec = (uint32_t)(tgt + 1);
+    if (a_me && tgt >= 0 && dmin < c.shoot_range) {
+      if (mun == 0) rec |= SLOT2_KILL;
+      else if (gun_available(c, mun, lf, step)) {
+        mun -= 1; lf = step;
+        io.st(TE_D_MUNITION, s, (uint32_t)mun); io.st(TE_D_LAST_FIRED, s, (uint32_t)step);
+        const U4 r = env_rng(c, env, RNG_HIT, (uint32_t)s, 0, episode, (uint32_t)step);
+        if (u01(r.x) < c.hit_prob) rec |= SLOT2_KILL;
+      }
+    }
+    if (a_me && tgt >= 0 && dmin < c.explosion_range) rec |= SLOT_EXPLODE;
+    *reinterpret_cast<uint2*>(&sm[R.prec2(s) * 64 + 2 * lane]) = make_uint2(rec, __float_as_uint(dmin));
+  }
+  TE_SLOT_BARRIER();
+
+  // ---- P3
+  const uint32_t S = L(R.accS()), zone = L(R.accZone());
+  uint32_t killed = 0u;
+  int shots = 0, exploded = 0;
+  float cur = 0.0f;   // stage02_agent_min_distance: the first armed pursuer's closest invader (0 when there is none), before any respawn
+  bool found = false;
+  for (int q = 0; q < P; ++q) {
+    const uint2 r = *reinterpret_cast<const uint2*>(&sm[R.prec2(q) * 64 + 2 * lane]);
+    const int t = (int)(r.x & 0xFFu) - 1;
+    if (!found && ((S >> q) & 1u)) { found = true; cur = t >= 0 ? __uint_as_float(r.y) : 0.0f; }
+    if (r.x & SLOT2_KILL) { killed |= 1u << t; shots += 1; }
+    if (r.x & SLOT_EXPLODE) { killed |= (1u << q) | (1u << t); exploded += 1; }
+  }
+  uint32_t A = S & ~killed;
+  if ((killed >> s) & 1u) io.disarm(s);
+  const bool outside_p = (zone & pur_bits) != 0u, outside_i = (zone & inv_bits) != 0u;
+  const bool term = step > max_step || outside_p || outside_i || __popc(A & pur_bits) < P;
+  const bool to_terminal = valid && term && c.auto_reset;
+  bool own = false;
+  if (s >= 1) {   // the observation is taken before the respawn: a drone armed after the step broadcast has no Delta = 1 snapshot yet
+    own = ((A >> s) & 1u) != 0u && rh < 1.0f;
+    for (uint32_t m = all_bits & ~1u & ~(1u << s); m; m &= m - 1u) {
+      const int k = __ffs((int)m) - 1;
+      const uint2 cr = *reinterpret_cast<const uint2*>(&sm[R.cellr(k) * 64 + 2 * lane]);
+      const float rk = __uint_as_float(cr.y);
+      const bool beaten = ((A >> k) & 1u) != 0u && cr.x == (uint32_t)cj && (rk < rh || (rk == rh && k < s));
+      own = own && !beaten;
+    }
+    if (own && valid) Lor(R.accOwn(), 1u << s);
+  }
+  const float flag_me = (float)(s < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
+  const bool time_plane = c.lidar_channels != 2;
+  auto patch = [&](float* dst) {
+    dst += (size_t)env * lidar_words(c);
+    dst[cj] = rh; dst[TE_LIDAR_CELLS + cj] = flag_me;
+    if (time_plane) dst[2 * TE_LIDAR_CELLS + cj] = 0.1f;
+  };
+  if (valid && own && !to_terminal && o.obs.lidar) patch(o.obs.lidar);
+  const unsigned long long term_b = __ballot(to_terminal);
+  if (o.term.lidar && term_b) {
+    for (unsigned long long tb = term_b; tb; tb &= tb - 1) {
+      const int l = __ffsll((long long)tb) - 1;
+      float* tile = o.term.lidar + (size_t)(blockIdx.x * 64 + l) * lidar_words(c);
+      for (int e = s * 64 + lane; e < lidar_words(c); e += 64 * D) tile[e] = 1.0f;
+    }
+  }
+  if (s == 0) {   // compute_reward (stages.py:241-300), outputs, env record
+    if (valid) {
+      io.stef(TE_E_LAST_ACTION + 0, act.x); io.stef(TE_E_LAST_ACTION + 1, act.y); io.stef(TE_E_LAST_ACTION + 2, act.z); io.stef(TE_E_LAST_ACTION + 3, act.w);
+      io.ste(TE_E_STEP, (uint32_t)step); io.ste(TE_E_SNAP_MASK, S);
+    }
+    kills += shots; deads += exploded;
+    float gs[3];
+    gun_state(c, mun, lf, step, max_munition_of(c, 0), gs);
+    const bool ready = gs[2] == 1.0f || gs[0] == 0.0f;
+    float bonus = 0.0f, penalty = 0.0f;
+    const float score = ready ? -cur : cur * (2.0f * gs[1] - 1.0f);
+    if (0.01f < last - cur && ready) bonus += c.approach_bonus_gain * fnorm(V3{ag[3], ag[4], ag[5]});
+    bonus += 1000.0f * (float)shots; penalty += 1000.0f * (float)exploded;
+    if (outside_p) penalty += 1000.0f;
+    const float reward = score + bonus - penalty;
+    if (valid) {
+      io.ste(TE_E_AGENT_KILLS, (uint32_t)kills); io.ste(TE_E_DEADS, (uint32_t)deads);
+      o.reward[env] = reward; o.done[env] = term ? 1 : 0;
+      reinterpret_cast<int4*>(o.info)[env] = make_int4(kills, 0, deads, 0);
+    }
+    if (to_terminal) {
+      if (o.term.inertial) inertial_row_regs(c, o.term.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, mx, my, mz, ag, mun, lf, step);
+      if (o.term.last_action) reinterpret_cast<float4*>(o.term.last_action)[env] = act;
+    }
+    if (valid) { io.stef(TE_E_PREV_SNAP_MIN, cur); io.stef(TE_E_LAST_DIST, cur); }   // on_step_end: last_offsets = current_offsets
+  }
+  // on_step_end: killed invaders come back (stages.py:167-174); an auto-reset respawns every drone (L3Stage1.on_reset, stages.py:104-131)
+  if (valid && !is_p && !((A >> s) & 1u)) {
+    const V3 w = stage02_invader_position(c, env, s, episode, (uint32_t)step);
+    io.respawn(c, s, w); mx = w.x; my = w.y; mz = w.z;
+  }
+  if (to_terminal) {
+    episode += 1u; step = 0;
+    if (s == 0) {
+      io.ste(TE_E_EPISODE, episode); io.ste(TE_E_STEP, 0u); io.ste(TE_E_MAX_STEP, (uint32_t)c.max_step); io.ste(TE_E_ROUND, 0u);
+      io.ste(TE_E_AGENT_KILLS, 0u); io.ste(TE_E_ALLIES_KILLS, 0u); io.ste(TE_E_DEADS, 0u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) io.ste(TE_E_LAST_ACTION + k, 0u);
+      io.ste(TE_E_SNAP_MASK, all_bits);
+    }
+    V3 w;
+    if (is_p) {
+      const U4 r = env_rng(c, env, RNG_SPAWN_PURSUER, (uint32_t)s, 0, episode, 0);
+      w = stage02_position(c.pursuer_spawn_radius, 0.0f, u01(r.x), u01(r.y), u01(r.z));
+      mun = max_munition_of(c, s); lf = -c.cooldown_steps;
+    } else w = stage02_invader_position(c, env, s, episode, 0u);
+    io.respawn(c, s, w); mx = w.x; my = w.y; mz = w.z;
+    act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ag[k] = 0.0f;
+  }
+  L(R.npos(0, s)) = __float_as_uint(mx); L(R.npos(1, s)) = __float_as_uint(my); L(R.npos(2, s)) = __float_as_uint(mz);
+  if (o.term.lidar && term_b) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TE_SLOT_BARRIER();
+
+  // ---- P4
+  if (s >= 1 && to_terminal && own && o.term.lidar) patch(o.term.lidar);
+  if (o.persist && o.obs.lidar && valid) {
+    const uint32_t owners = L(R.accOwn());
+    uint16_t* pv = o.prev + env;
+    if (s == 0) pv[0] = (uint16_t)(to_terminal ? 0 : __popc(owners));
+    else if (own && !to_terminal) pv[(size_t)(__popc(owners & ((1u << s) - 1u)) + 1) * p.Npad] = (uint16_t)cj;
+  }
+  if (s == 0) {
+    if (to_terminal) {   // closest invader of pursuer 0 on the fresh positions
+      float d0 = 0.0f; bool any = false;
+      for (int j = P; j < D; ++j) {
+        const float d = fdist(V3{mx, my, mz}, V3{Lf(R.npos(0, j)), Lf(R.npos(1, j)), Lf(R.npos(2, j))});
+        const bool take = !any || d < d0;
+        d0 = take ? d : d0; any = true;
+      }
+      io.stef(TE_E_PREV_SNAP_MIN, d0); io.stef(TE_E_LAST_DIST, d0);
+    }
+    if (o.obs.inertial && valid) inertial_row_regs(c, o.obs.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, mx, my, mz, ag, mun, lf, step);
+    if (valid && o.obs.last_action) reinterpret_cast<float4*>(o.obs.last_action)[env] = act;
+  }
+  if (s == D - 1) {   // every armed slot flies as a dense wave outside the level4 family; the invaders are all armed again
+    const uint32_t armed_post = to_terminal ? all_bits : ((A & pur_bits) | (valid ? inv_bits : 0u));
+    uint64_t dense = 0u;
+    for (int k = 0; k < D; ++k) if (__ballot(valid && ((armed_post >> k) & 1u))) dense |= (uint64_t)1 << k;
+    if (lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = 0u; p.live_mask[blockIdx.x] = dense; }
+  }
 }
 
 }  // namespace te

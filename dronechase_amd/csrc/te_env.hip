@@ -992,7 +992,11 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   // one wave per (chunk, slot) instead of one wave per chunk: a shard with fewer chunks than the chip has SIMDs is one dependent chain per
   // wave, and the chain is what the slot waves shorten (te_engage_slots.hpp); large shards keep engage_kernel (fewer instructions in total)
   if (regs_l4 && !cfg->stacked_obs && D <= kSlotWaves && cfg->n_pursuers <= kSlotPursuers && cfg->reward_model == TE_REWARD_EXP03 && !cfg->drone_contact) {
-    e->engage_slots = cfg->n_envs <= kSlotsMaxEnvs ? 1 : 0;
+    e->engage_slots = (long long)cfg->n_envs * D <= kSlotsMaxPairs ? 1 : 0;
+    if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "slots")) e->engage_slots = 1; else if (!strcmp(v, "regs")) e->engage_slots = 0; }
+  }
+  if (e->family == FAM_STAGE02 && e->engage_regs == 3) {   // stage02 in the same form (engage_slots_stage02_kernel)
+    e->engage_slots = (long long)cfg->n_envs * D <= kSlotsMaxPairs ? 1 : 0;
     if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "slots")) e->engage_slots = 1; else if (!strcmp(v, "regs")) e->engage_slots = 0; }
   }
   if (D > kMaxD && !(regs_l4 && cfg->stacked_obs))
@@ -1302,7 +1306,8 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   StepOut o{reward, done, info, ObsOut{stack ? nullptr : obs_lidar, obs_inertial, obs_last_action},
             ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}, e->prev_cells, stack ? 0 : persist};
   const bool contact = p.cfg.drone_contact != 0;   // its own instantiations: the contact pass would cost every launch ~150 VGPRs
-  if (e->engage_slots && !contact) TE_LAUNCH((engage_slots_kernel<kSlotWaves>), dim3(b2), dim3(64 * p.D), (size_t)slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
+  if (e->engage_slots && e->family == FAM_STAGE02) TE_LAUNCH((engage_slots_stage02_kernel<kSlotWaves>), dim3(b2), dim3(64 * p.D), (size_t)slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
+  else if (e->engage_slots && !contact) TE_LAUNCH((engage_slots_kernel<kSlotWaves>), dim3(b2), dim3(64 * p.D), (size_t)slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
   else if (e->engage_regs == 1 && !contact) TE_LAUNCH((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, p, actions, o);
   else if (e->engage_regs == 2 && !contact) TE_LAUNCH((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, p, actions, o);
 #ifndef TE_DEBUG_STAMPS  // the stamp build leaves the contact variants out (the compiler rejects them next to the stamp stores)

@@ -197,6 +197,7 @@ TE_DEV V3 level4_position(const te_config& c, float r, float u_theta, float u_ph
 }
 // L3Stage1.generate_positions (level3/components/stages.py:360-376)
 TE_DEV V3 stage02_position(float r, float r_max, float u_r, float u_theta, float u_phi) {
+  TE_EXACT   // (inlined into engage_stage02_kernel and engage_slots_stage02_kernel, whose respawns are compared bitwise)
   if (r > r_max) r_max = r;
   float radius = r + u_r * (r_max - r);
   float theta = u_theta * 2.0f * kPi, phi = u_phi * kPi * 0.5f;
@@ -258,6 +259,18 @@ TE_DEV void cmd_toward(V3 from, V3 to, float speed, float out[3]) {
   float n = norm(d);
   float inv = n > 0.0f ? 1.0f / n : 1.0f;  // zero vector stays zero (…air_combat_only.py:191-195)
   command_to_velocity(d.x * inv, d.y * inv, d.z * inv, speed, out[0], out[1], out[2]);
+}
+// cmd_toward + Quadcopter.convert_command_to_setpoint (te_device.hpp: command_to_velocity) for the behaviour tree's command, in exact
+// arithmetic (te_device.hpp): prepare_slot (after te_reset / te_set_state) and the engage kernels (during a rollout) must write the same bits
+TE_DEV void x_cmd_toward(V3 from, V3 to, float speed, float out[3]) {
+  TE_EXACT
+  const float dx = to.x - from.x, dy = to.y - from.y, dz = to.z - from.z;
+  const float n = sqrtf(xfma(dz, dz, xfma(dy, dy, dx * dx)));
+  const float inv = n > 0.0f ? 1.0f / n : 1.0f;  // zero vector stays zero (…air_combat_only.py:191-195)
+  const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+  const float m = sqrtf(xfma(uz, uz, xfma(uy, uy, ux * ux)));
+  const float inv2 = 1.0f / (m > 0.0f ? m : 1.0f);
+  out[0] = speed * (ux * inv2); out[1] = speed * (uy * inv2); out[2] = speed * (uz * inv2);
 }
 // GeometryUtils.is_point_inside_cone (geometry_utils.py:6-29)
 TE_DEV bool inside_cone(V3 p, V3 apex, V3 base, float degrees) {
@@ -330,9 +343,9 @@ template <class V> TE_DEV void prepare_slot(const te_config& c, const V& v, int 
       float dm;
       int t = ((S >> s) & 1u) ? closest_invader(v, S, s, dm) : -1;
       V3 target = t >= 0 ? obs_pos(v, t) : V3{0, 0, 0};
-      cmd_toward(me, target, c.ally_speed, out);
+      x_cmd_toward(me, target, c.ally_speed, out);
     } else {
-      cmd_toward(me, V3{v.gf(TE_D_FORMATION, s), v.gf(TE_D_FORMATION + 1, s), v.gf(TE_D_FORMATION + 2, s)}, c.ally_speed, out);
+      x_cmd_toward(me, V3{v.gf(TE_D_FORMATION, s), v.gf(TE_D_FORMATION + 1, s), v.gf(TE_D_FORMATION + 2, s)}, c.ally_speed, out);
     }
   } else if (ext || c.ally_policy != TE_ALLY_FROZEN) {  // (frozen: exp04_vFinal_task.py:240-242: drive([0,0,0,1]))
     // nobody, or the caller's policy (te_set_ally_actions, exp05): the set-point persists
