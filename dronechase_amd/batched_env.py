@@ -41,6 +41,7 @@ class BatchedEnv:
         self.reward = torch.empty((N,), **f32)
         self.done = torch.empty((N,), dtype=torch.uint8, device=dev)
         self.info = torch.empty((N, K.INFO_WORDS), dtype=torch.int32, device=dev)
+        self.generation = 0   # number of env.step calls so far: the t_* (terminal) buffers hold the rows of the LAST step only
         self.stacked_mode = bool(cfg.stacked_obs)
         if self.stacked_mode:  # level5: FusedLIDAR stacked observation instead of the own sphere
             shape = (N, K.STACK_SPHERES, K.LIDAR_CHANNELS, K.LIDAR_NTHETA, K.LIDAR_NPHI)
@@ -108,6 +109,7 @@ class BatchedEnv:
         _lib.check(self.L.te_step(self._h, self._p(a), self._p(lidar), self._p(inertial),
                                   self._p(last_action), self._p(self.reward), self._p(self.done), self._p(self.info),
                                   self._p(t[0]), self._p(t[1]), self._p(t[2]), self._stream()), "te_step")
+        self.generation += 1
         return lidar, inertial, last_action, self.reward, self.done, self.info
 
     # level5 ---------------------------------------------------------------------------------
@@ -122,12 +124,16 @@ class BatchedEnv:
         _lib.check(self.L.te_step_stacked(self._h, self._p(a), self._p(self.stacked), self._p(self.mask), self._p(self.inertial),
                                           self._p(self.last_action), self._p(self.reward), self._p(self.done), self._p(self.info),
                                           self._p(t[0]), self._p(t[1]), self._p(t[2]), self._p(t[3]), self._stream()), "te_step_stacked")
+        self.generation += 1
         return self.stacked, self.mask, self.inertial, self.last_action, self.reward, self.done, self.info
 
     def set_persistent_obs(self, on: bool = True) -> None:
         """Promise that nobody but the library writes the LIDAR observation buffers.  While the same buffer keeps being passed (this
         object's own `lidar` / `stacked` / `_students` tensors are, unless step(out=...) names another one), a step rewrites only the
-        cells that change instead of streaming the whole background first (te_set_persistent_obs)."""
+        cells that change instead of streaming the whole background first (te_set_persistent_obs).  The library recognises "the same buffer" by
+        its ADDRESS: a tensor passed through step(out=...) that is freed and whose memory the caching allocator hands to a new tensor of the
+        same shape would be taken for the old one.  Keep the tensor alive for as long as it is passed, or switch the mode off and on again
+        (which forgets the buffer) when the out tensor changes."""
         _lib.check(self.L.te_set_persistent_obs(self._h, 1 if on else 0), "te_set_persistent_obs")
 
     def step_students(self):

@@ -64,7 +64,13 @@ static void cf2x_recalled(te_quad_params* q) {
 /* THE DEFAULT OF EVERY TASK (round 3): the recalled table with the fewest changed entries that reproduce the recorded PyBullet
  * observations (src/core/rl_framework/utils/output/collect_and_save/io_data0.h5) within their motor-noise scatter under the
  * reference's loop as it reads (update_control on every 240 Hz sub-step, level4_simulation.py:92-94): tools/physics_fit.py,
- * DESIGN.md 5, profiles/r03_physics_fit_headline.md.  A fit to 147 numbers, not a verified table: PyBullet parity stays unpinned. */
+ * DESIGN.md 5, profiles/r03_physics_fit_headline.md.  A fit to 147 numbers with 21 fitted nuisance values, NOT a verified table, and
+ * not the only one the recording supports: in units of its OWN (4-5 x smaller) motor-noise scatter this table scores chi^2 / dof 2.8
+ * (the recalled one 5.3) and e.g. "120 Hz control + ang_pos_kp x 2 + total_thrust x 2" scores 0.29 — the data do not identify the
+ * entries (only the product kp * arm * thrust / inertia of the rate loop and a slower vertical channel).  It is the default because it is
+ * the smallest change that passes under the reference's loop as it reads; te_quad_preset(cfg, TE_QUAD_CF2X_RECALLED) restores PyFlyt's
+ * table as recalled.  PyBullet parity of the quadrotor dynamics stays UNPINNED under either preset
+ * (tests/test_oracle_physics.py asserts both yardsticks). */
 static void cf2x_recorded_fit(te_quad_params* q) {
   cf2x_recalled(q);
   /* tools/physics_fit.py: chi^2 / dof 5.3 -> 0.29 against the 147 recorded numbers with these two entries:

@@ -46,9 +46,12 @@ class LazyInfos(Sequence):
     """infos without materialising N dicts per step: dicts are built on access.  `info` / `done` may be zero-argument callables
     (output="torch": nothing crosses PCIe, and the stream is not drained, unless somebody actually reads an info)."""
 
-    def __init__(self, info, done, terminal):
+    def __init__(self, info, done, terminal, still_valid=None):
         self._info, self._done, self._terminal = info, done, terminal
         self._n = None if callable(done) else len(done)
+        # output="torch": the terminal observations are VIEWS of the backend's terminal buffers, which hold the rows of the step that produced
+        # these infos and are rewritten by the next one.  `still_valid()` turns a late read into an error instead of another step's rows.
+        self._still_valid = still_valid
 
     def _host(self):
         if callable(self._info):
@@ -68,8 +71,16 @@ class LazyInfos(Sequence):
         d = {"agent_kills": int(r[0]), "allies_kills": int(r[1]), "deads": int(r[2]), "current_wave": int(r[3]),
              "TimeLimit.truncated": False}  # the reference always returns truncated=False (exp03_vFinal_environment.py:167)
         if done[i] and self._terminal is not None:
+            if self._still_valid is not None and not self._still_valid():
+                raise RuntimeError("infos[i]['terminal_observation'] was read after a later step(): with output='torch' the terminal observations are "
+                                   "views of device buffers that hold the LAST step's rows only (counters, done and the key itself stay valid). "
+                                   "Read them before the next step, or clone the rows you keep.")
             d["terminal_observation"] = {k: v[i] for k, v in self._terminal.items()}
         return d
+
+    def has_terminal_observation(self, i) -> bool:
+        """Whether env i finished an episode in the step these infos belong to (valid for ever, unlike the rows themselves)."""
+        return bool(self._host()[1][i]) and self._terminal is not None
 
     def materialise(self) -> List[Dict[str, Any]]:
         """The list of N dicts SB3 iterates over (infos="dicts"): one C-level conversion of the info rows, then a dict display per env."""
@@ -228,7 +239,9 @@ class ThreatEngageVecEnv(_SB3VecEnv):  # type: ignore[misc]
                     host["info"], d = fetch()
                     host["done"] = d.astype(bool)
                 return host
-            infos = LazyInfos(lambda: both()["info"], lambda: both()["done"], tbuf)
+            gen = getattr(b, "generation", None)   # (backends without a step counter: no lifetime check)
+            infos = LazyInfos(lambda: both()["info"], lambda: both()["done"], tbuf,
+                              still_valid=None if gen is None else (lambda: b.generation == gen))
             if self.infos_mode == "dicts":
                 infos = infos.materialise()
             return dict(zip(self._obs_keys(), obs_t)), reward, done.bool(), infos

@@ -52,11 +52,12 @@ def _compare_states(so, sg, N, D):
     do, eo = _split(so, N, D)
     dg, eg = _split(sg, N, D)
     from dronechase_amd import config as K
-    # the drone's state proper (pose, velocities, throttles, IMU reads, set-point) is held to STATE_TOL; the controller's memories (PID
-    # integrators and previous errors, K.D PID_AV_I .. PID_ZV_E) to 2 x STATE_TOL: the previous rate error is a difference of two rad/s
-    # quantities that the stiff rate loop of the default table (ang_vel_kp x 6) amplifies — 5.7e-5 already between the float32 and the
-    # float64 oracle under control_every_substep = 0
-    scale = np.array([0.5 if K.D["PID_AV_I"] <= w < K.D["SETPOINT"] else 1.0 for w in fd])
+    # EVERY float word is held to STATE_TOL, the controller's memories included.  Measured per word group on the MI355X (tools/parity_margins.py,
+    # profiles/r04_e_parity_margins.txt; 5 task variants x motor noise on / off x 8 checkpoints x 2 048 envs): pose / velocities <= 5.2e-5,
+    # throttles <= 9.3e-6, the previous rate error PID_AV_E <= 8.7e-5 (control_every_substep = 0; 4.3e-5 under either quadrotor table with the
+    # reference's loop), every other PID word <= 1.1e-6, IMU reads <= 3.6e-5.  (Round 3 had relaxed the PID words to 2 x STATE_TOL when the
+    # recorded-fit table became the default; the measurement shows that no word needs it.)
+    scale = np.ones(len(fd))
     fdiff = (np.abs(do[..., fd].view(np.float32).astype(np.float64) - dg[..., fd].view(np.float32)) * scale).reshape(N, -1).max(1)
     ediff = np.abs(eo[:, fe].view(np.float32).astype(np.float64) - eg[:, fe].view(np.float32)).max(1)
     imis = (do[..., idw] != dg[..., idw]).any(axis=(1, 2)) | (eo[:, iew] != eg[:, iew]).any(axis=1)
@@ -147,7 +148,10 @@ def test_rollout_parity_from_reset(task):
         np.testing.assert_allclose(grew[rew_ok], orew[rew_ok], rtol=1e-4, atol=2e-2)
         np.testing.assert_allclose(gi[clean], oi[clean], atol=2e-4)
     diff, imis = _compare_states(orc.get_state(), gpu.get_state().cpu().numpy().view(np.uint32), N, D)
-    assert clean.mean() > 0.5
+    # measured on the MI355X (tools/parity_margins.py): 0.963 (exp03), 0.992 (stage01), 0.996 (stage02) of the envs never come within 1e-3 of a
+    # state-changing threshold in 120 steps; the bound leaves 3 points of margin for another seed, not half of the envs
+    print(f"{task}: clean fraction {clean.mean():.3f}")
+    assert clean.mean() > {"exp03": 0.93, "stage01": 0.96, "stage02": 0.96}[task]
     assert not (imis & clean).any()
     assert diff[clean].max() < 5e-3  # 120 env-steps = 1920 sub-steps of float32 drift, closed-loop
     gpu.close(); orc.close()

@@ -181,6 +181,13 @@ def test_recorded_first_steps_against_the_two_quadrotor_presets():
         assert lo < fit["ratios"][name][0] and fit["ratios"][name][1] < hi, (name, fit["ratios"][name])
     for w in range(F.W):
         assert 0.4 < fit["zv_i"][w] < 0.75
+    # The second yardstick (round-3 review): each table scored in units of ITS OWN motor-noise scatter (the default flies calmer, its scatter
+    # is 4-5 x smaller).  There the default does NOT pass either (chi^2 / dof 2.8 at the end of round 3; the recalled table 5.3), and other
+    # candidates of tools/physics_fit.py fit as well or better (120 Hz control + ang_pos_kp x 2 + total_thrust x 2: 0.20 / 0.29): the recording
+    # does not identify the entries, the default is ONE of several tables it supports, and PyBullet parity stays unpinned.
+    own = F.row("te_config_default, own noise", default, F.noise_sigma(default, 150))
+    assert 1.0 < own["chi2_dof"] < 5.0, own["chi2_dof"]
+    assert own["chi2_dof"] < chi2 / F.DOF               # still the better of the two presets under either yardstick
 
 
 @pytest.mark.parametrize("preset", [1, 0])

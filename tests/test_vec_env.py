@@ -151,13 +151,26 @@ def test_lazy_infos_on_gpu_survive_the_next_step():
     for s in range(16):
         a = v.backend.random_actions(9, s)
         held.append(v.step(a)[3]); eager.append(w.step(a)[3])
-    saw_done = 0
-    for lazy, now in zip(held, eager):          # the lazy infos are only read here, 1..16 steps late
+    saw_done = late_errors = 0
+    for k, (lazy, now) in enumerate(zip(held, eager)):          # the lazy infos are only read here, 0..15 steps late
+        last = k == len(held) - 1
         for e in range(n):
-            assert {k: lazy[e][k] for k in ("agent_kills", "allies_kills", "deads", "current_wave")} == {k: now[e][k] for k in ("agent_kills", "allies_kills", "deads", "current_wave")}
-            assert ("terminal_observation" in lazy[e]) == ("terminal_observation" in now[e])
-            saw_done += "terminal_observation" in now[e]
-    assert saw_done >= n
+            ended = "terminal_observation" in now[e]
+            assert lazy.has_terminal_observation(e) == ended
+            saw_done += ended
+            if ended and not last:
+                # the counters of step k survive; its terminal ROWS do not (views of the backend's buffers): a late read must fail loudly
+                # instead of handing out another step's rows (round-3 review)
+                with pytest.raises(RuntimeError, match="LAST step"):
+                    lazy[e]
+                late_errors += 1
+                continue
+            got = lazy[e]
+            assert {k2: got[k2] for k2 in ("agent_kills", "allies_kills", "deads", "current_wave")} == {k2: now[e][k2] for k2 in ("agent_kills", "allies_kills", "deads", "current_wave")}
+            if ended:   # the last step's rows are still there, and they are the eager env's rows
+                for key in ("lidar", "inertial_data", "last_action"):
+                    assert torch.equal(got["terminal_observation"][key], now[e]["terminal_observation"][key])
+    assert saw_done >= n and late_errors > 0
     v.close(); w.close()
 
 

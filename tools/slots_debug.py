@@ -7,10 +7,11 @@ from dronechase_amd import default_config, config as K
 from dronechase_amd.batched_env import BatchedEnv
 
 task, n, steps = sys.argv[1] if len(sys.argv) > 1 else "stage03", int(sys.argv[2]) if len(sys.argv) > 2 else 8192, int(sys.argv[3]) if len(sys.argv) > 3 else 40
+over = dict(kv.split("=") for kv in sys.argv[4:]); over = {k: int(v) for k, v in over.items()}
 envs = []
 for mode in ("slots", "regs"):
     os.environ["TE_ENGAGE"] = mode
-    envs.append(BatchedEnv(default_config(task, n_envs=n), "cuda:0"))
+    envs.append(BatchedEnv(default_config(task, n_envs=n, **over), "cuda:0"))
 a, b = envs
 a.reset(); b.reset()
 names = ["lidar", "inertial", "last_action", "reward", "done", "info"]
