@@ -28,10 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# VALU issue model of the sub-step kernel ("report VALU utilisation next to HBM %"): static count of
-# the loop body, 4 clocks per wave64 VALU instruction, 16 for the quarter-rate ones (tools/loop_cost.py), 1024 SIMDs,
-# 2.4 GHz (rocm-smi reads 2.397 GHz for the whole bench)
-VALU_CLOCKS_PER_DRONE_SUBSTEP = 1950.0
+# VALU utilisation of the sub-step kernel ("report VALU utilisation next to HBM %") comes from the committed counters
+# (profiles/pmc_valu_latest.json, tools/pmc_valu.sh: SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs against GRBM_GUI_ACTIVE / 8), like `traffic` from
+# profiles/pmc_latest.json.  (Rounds 1-3 printed a static model, 1 950 clocks per armed-drone sub-step = 0.81 of the launch; the counters read
+# 1 351 busy cycles per armed-drone sub-step = 0.51: the model priced the quarter-rate instructions at 16 clocks, the hardware issues them in 8.)
 SIMDS, CLOCK_HZ, SUBSTEPS = 1024, 2.4e9, 16
 
 
@@ -398,14 +398,36 @@ def main():
                         traffic_source = f"profiles/pmc_latest.json ({rec.get('source', 'separate rocprofv3 --pmc passes of this command')}): not measured in this run"
                     except Exception:
                         traffic = None
+                valu = {}
+                try:   # the VALU side of the same launch, from the committed counters (never a model)
+                    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu_latest.json")))
+                    k1 = rec["substeps_kernel"]
+                    cyc = k1["valu_busy_cycles_per_drone_substep"]
+                    valu = {"valu_busy_frac_substeps_kernel_pmc": k1["valu_busy_frac"],   # measured: the profiled command (stage03, 65 536 envs, driver window)
+                            "valu_busy_cycles_per_drone_substep_pmc": cyc, "valu_instructions_per_drone_substep_pmc": k1["valu_instructions_per_drone_substep"],
+                            # this run's launch priced with the measured cycles per armed-drone sub-step, at the 2.4 GHz the chip holds in this bench
+                            "valu_busy_frac_substeps_kernel": (armed * n_local / 64.0) * SUBSTEPS * cyc / (SIMDS * CLOCK_HZ * k1_ms * 1e-3),
+                            "valu_source": "profiles/pmc_valu_latest.json (" + rec.get("source", "") + "): not measured in this run"}
+                except Exception:
+                    pass
                 out["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                                    "algorithmic_bytes_per_launch": dom_bytes * n_local, "avg_launch_ms": dom_ms,
                                    "launches_timed": n_prof, "timed_in": timed_in,
-                                   "armed_drones_per_env": armed,
-                                   "valu_issue_frac_substeps_kernel": (armed * n_local / 64.0) * SUBSTEPS * VALU_CLOCKS_PER_DRONE_SUBSTEP
-                                                                      / (SIMDS * CLOCK_HZ * k1_ms * 1e-3),
+                                   "armed_drones_per_env": armed, **valu,
                                    "armed_drones_per_env_begin_end": head["armed_drones_per_env_begin_end"]}
+                # the other kernel of the step next to it (round-3 review: its fraction and traffic ratio belong in the headline too)
+                oth_ms, oth_name, oth_bytes = min((k1_ms, "substeps_kernel", b_k1), (k2_ms, "engage_observe_kernel", alg_k2))
+                oth = {"kernel": oth_name, "avg_launch_ms": oth_ms, "algorithmic_bytes_per_launch": oth_bytes * n_local,
+                       "frac": oth_bytes * n_local / (oth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if traffic is not None:
+                    try:
+                        t2 = json.load(open(pmc)).get(oth_name, {}).get("hbm_bytes_per_launch")
+                        if t2:
+                            oth["traffic"] = t2; oth["traffic_over_algorithmic"] = t2 / (oth_bytes * n_local)
+                    except Exception:
+                        pass
+                out["roofline"]["other_kernel"] = oth
             step_ms = 1e3 * elapsed / args.steps
             out["roofline_env_step"] = {"bound": "hbm", "achieved": alg * n_local / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": alg * n_local / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

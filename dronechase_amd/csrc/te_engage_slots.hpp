@@ -105,20 +105,12 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
     w_last_dist = io.le(TE_E_LAST_DIST); w_ak = io.le(TE_E_AGENT_KILLS); w_lk = io.le(TE_E_ALLIES_KILLS); w_dd = io.le(TE_E_DEADS);
     if (valid) act = reinterpret_cast<const float4*>(actions)[env];
   }
-  // pursuer waves: gun, formation point, and every live invader's row
+  // pursuer waves: gun and formation point (their targeting reads the invaders' rows from LDS behind barrier 1: no per-wave register arrays,
+  // 64 VGPRs = eight waves per SIMD, two workgroups of eleven waves per CU)
   uint32_t w_mun = 0u, w_lf = 0u; float fx = 0.0f, fy = 0.0f, fz = 0.0f;
-  float qx[DM], qy[DM], qz[DM]; uint32_t qa[DM];
-#pragma unroll
-  for (int j = 0; j < DM; ++j) { qx[j] = qy[j] = qz[j] = 0.0f; qa[j] = 0u; }
   if (is_p) {
     w_mun = io.ld(TE_D_MUNITION, s); w_lf = io.ld(TE_D_LAST_FIRED, s);
     fx = io.ldf(TE_D_FORMATION, s); fy = io.ldf(TE_D_FORMATION + 1, s); fz = io.ldf(TE_D_FORMATION + 2, s);
-#pragma unroll
-    for (int j = 1; j < DM; ++j) {
-      if ((live >> j) & ~pur_bits >> j & 1u) {
-        qx[j] = io.ldf(TE_D_OBS_POS, j); qy[j] = io.ldf(TE_D_OBS_POS + 1, j); qz[j] = io.ldf(TE_D_OBS_POS + 2, j); qa[j] = io.ld(TE_D_ARMED, j);
-      }
-    }
   }
   // an opaque zero, defined HERE: a comparison against it cannot be scheduled in front of this line.  (Comparing a requested word with the
   // literal 0 lets the compiler sink the test, and the wait for the word, into the branch that requested it: every live invader's row then
@@ -149,14 +141,18 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
     lidar_cell_fast(c, x_mul(Rm, sub(V3{mx, my, mz}, apos)), cj, rh);
     *reinterpret_cast<uint2*>(&sm[R.cellr(s) * 64 + 2 * lane]) = make_uint2((uint32_t)cj, __float_as_uint(rh));
   }
+  TE_WSTAMP(2, 0);
+  TE_SLOT_BARRIER();
+  TE_WSTAMP(3, 0);
+  const uint32_t S = L(R.accS()), zone = L(R.accZone()), org = L(R.accOrg());
   // ---- pursuer wave: identify_closest_invader (offsets_handler.py:256-281), process_shoot_range_invaders /
   // process_explosion_range_invaders (exp03_vFinal_task.py:359-413) for ITS pursuer: none of it depends on another pursuer's outcome
   if (is_p) {
     int tgt = -1; float dmin = 0.0f;
-#pragma unroll
-    for (int j = 1; j < DM; ++j) {   // strict '<' in slot order
-      const float d = fdist(V3{mx, my, mz}, V3{qx[j], qy[j], qz[j]});
-      const bool take = a_me != 0u && qa[j] != zero && (tgt < 0 || d < dmin);   // (qa is zero for pursuers, dead slots and slots >= D)
+    for (uint32_t m = live & inv_bits; m; m &= m - 1u) {   // strict '<' in slot order, over the slots somebody of the chunk has armed
+      const int j = __ffs((int)m) - 1;
+      const float d = fdist(V3{mx, my, mz}, V3{Lf(R.pos(0, j)), Lf(R.pos(1, j)), Lf(R.pos(2, j))});
+      const bool take = a_me != 0u && ((S >> j) & 1u) != 0u && (tgt < 0 || d < dmin);
       tgt = take ? j : tgt;
       dmin = take ? d : dmin;
     }
@@ -173,12 +169,9 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
     if (a_me && tgt >= 0 && dmin < c.explosion_range) rec |= SLOT_EXPLODE | (mun == 0 ? SLOT_SUICIDE : 0u);
     L(R.prec(s)) = rec;
   }
-  TE_WSTAMP(2, 0);
-  TE_SLOT_BARRIER();
-  TE_WSTAMP(3, 0);
+  TE_SLOT_BARRIER();   // barrier 1b: the pursuers' records
 
   // ---- P3: the engagement, by every wave ----------------------------------------------------------------------------------
-  const uint32_t S = L(R.accS()), zone = L(R.accZone()), org = L(R.accOrg());
   uint32_t killed = 0u;
   int agent_shots = 0, ally_shots = 0, exploded = 0, pursuer_suicided = 0, agent_suicided = 0;
   for (int q = 0; q < P; ++q) {

@@ -9,8 +9,9 @@ from dronechase_amd.batched_env import BatchedEnv
 task, n, steps = sys.argv[1] if len(sys.argv) > 1 else "stage03", int(sys.argv[2]) if len(sys.argv) > 2 else 8192, int(sys.argv[3]) if len(sys.argv) > 3 else 40
 over = dict(kv.split("=") for kv in sys.argv[4:]); over = {k: int(v) for k, v in over.items()}
 envs = []
-for mode in ("slots", "regs"):
-    os.environ["TE_ENGAGE"] = mode
+VAR, A, B = os.environ.get("AB_VAR", "TE_ENGAGE"), os.environ.get("AB_A", "slots"), os.environ.get("AB_B", "regs")   # e.g. AB_VAR=TE_K1_HELP AB_A=1 AB_B=0
+for mode in (A, B):
+    os.environ[VAR] = mode
     envs.append(BatchedEnv(default_config(task, n_envs=n, **over), "cuda:0"))
 a, b = envs
 a.reset(); b.reset()
