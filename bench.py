@@ -441,7 +441,7 @@ def main():
         return out
 
     # te_step enqueues on the caller's stream (BatchedEnv passes torch's current one): the legacy null stream unless --own-stream.
-    # Interleaved A/B on one box (tools/ab_stream.sh, round 3): 851 / 851 / 861 M env-steps/s on the null stream against 848 / 855 / 846 M on a
+    # Interleaved A/B on one box (round 3): 851 / 851 / 861 M env-steps/s on the null stream against 848 / 855 / 846 M on a
     # stream of the bench's own in the driver's window — no difference.
     import contextlib
     lane = torch.cuda.stream(torch.cuda.Stream(device)) if args.own_stream else contextlib.nullcontext()

@@ -174,3 +174,26 @@ def test_training_run_at_16k_envs():
     assert logs[-1]["episodes_finished"] >= 0 and 0.0 <= logs[-1]["clip_frac"] <= 1.0
     print(f"PPO at {N} envs: {2 * 32 * N / dt / 1e6:.2f} M env-steps/s collect + update")
     env.close()
+
+
+@pytest.mark.gpu
+def test_fast_learner_switch_trains_with_finite_losses():
+    """PPOConfig.fast_learner (fused Adam + bf16 autocast of the policy's forward / backward, fp32 master weights and losses): two updates on
+    real rollouts of 4 096 stage03 envs; every statistic finite, the parameters move, and they stay fp32."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    from dronechase_amd.ppo import PPO, PPOConfig
+    env = BatchedEnv(default_config("stage03", n_envs=4096), "cuda:0")
+    ppo = PPO(env, PPOConfig(n_steps=16, batch_size=8192, n_epochs=2, use_graph=True, fast_learner=True), seed=5)
+    before = torch.cat([p.detach().flatten() for p in ppo.policy.parameters()]).clone()
+    logs = []
+    ppo.learn(2 * 16 * 4096, log=logs.append)
+    after = torch.cat([p.detach().flatten() for p in ppo.policy.parameters()])
+    assert len(logs) == 2 and all(np.isfinite(v) for e in logs for v in e.values())
+    assert torch.isfinite(after).all() and not torch.equal(before, after)
+    assert all(p.dtype == torch.float32 for p in ppo.policy.parameters())
+    assert 0.0 <= logs[-1]["clip_frac"] <= 1.0 and logs[-1]["entropy"] > 0
+    env.close()
