@@ -27,10 +27,10 @@ namespace te {
 
 constexpr int kSlotWaves = 16;     // waves of a chunk's workgroup = drone slots served (1 024 threads)
 constexpr int kSlotPursuers = 4;   // pursuers served (the exp tasks have 2)
-// te_create's default: shards of up to this many (env, slot) pairs take the slot waves; above it engage_kernel's single wave per chunk issues fewer
-// instructions in total and the chip is full either way (stage03: 18.1 vs 20.4 us at 32 768 envs, 24.6 vs 23.7 at 49 152, 31.0 vs 27.5 at 65 536;
-// exp02, 7 slots: 17.9 vs 19.0 at 65 536; profiles/r04_c_ab_engage_slots.txt)
-constexpr int kSlotsMaxPairs = 460000;
+// te_create's default: every shard size takes the slot waves since dead-slot waves retire early (round 4: stage03 x 65 536, driver's window
+// 18.4 vs 21.6 us, steady state and all-armed a tie; x 32 768: 14.2 vs 20.1; x 8 192: 10.4 vs 16.9 us; profiles/r04_j_ab_engage_slots_v4.txt);
+// TE_ENGAGE=regs brings engage_kernel back, and a te_env above this many (env, slot) pairs keeps it
+constexpr long long kSlotsMaxPairs = 1ll << 40;
 
 struct SlotRows {  // LDS rows of 64 words
   int D, P;
@@ -85,6 +85,16 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
   const uint32_t* __restrict__ lm32 = reinterpret_cast<const uint32_t*>(p.live_mask);
   const uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane(lm32[2 * blockIdx.x]) & all_bits;   // D <= 16
   const bool mine_live = is_p || ((live >> s) & 1u);
+  // A slot nobody of the chunk has armed AND that no env of the chunk can arm in this step (an env arms the invaders of its NEXT round, or
+  // of round 1 after a reset) has nothing to do: its wave retires on one plane row, before the first barrier (s_barrier does not wait for
+  // ended waves), and leaves its SIMD slot to the next workgroup — in a rollout 5-8 of stage03's 11 slots are live.  The one word such a
+  // slot would get, NAV_STATE = Wait in the envs that start a round (spawn_slot_at), is written by wave 0.
+  auto next_round_of = [&](int r) { return r + (r < c.n_rounds ? 1 : c.n_rounds); };   // advance_round (exp03_vFinal_task.py:155-175)
+  auto may_be_spawned = [&](int slot, int r) { const int i = slot - P; return i < invaders_in_round(c, next_round_of(r)) || i < invaders_in_round(c, 1); };
+  if (!mine_live) {
+    const int r = (int)io.le(TE_E_ROUND);
+    if (__ballot(valid && may_be_spawned(s, r)) == 0ull) return;
+  }
   // (a slot nobody of the chunk has armed is requested all the same: a conditional request makes the compiler wait for it inside the branch,
   // in front of every later request; its lanes are masked below)
   float mx = io.ldf(TE_D_OBS_POS, s), my = io.ldf(TE_D_OBS_POS + 1, s), mz = io.ldf(TE_D_OBS_POS + 2, s);
@@ -221,11 +231,11 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
   if (valid && own && !to_terminal && o.obs.lidar) patch(o.obs.lidar);
   // terminal tiles: ones, every wave its share; acknowledged before barrier 2, behind which the owners patch them
   const unsigned long long term_b = __ballot(to_terminal);
-  if (o.term.lidar && term_b) {
+  if (o.term.lidar && term_b && is_p) {   // (the pursuer waves: an invader wave may have retired)
     for (unsigned long long tb = term_b; tb; tb &= tb - 1) {
       const int l = __ffsll((long long)tb) - 1;
       float* tile = o.term.lidar + (size_t)(blockIdx.x * 64 + l) * lidar_words(c);
-      for (int e = s * 64 + lane; e < lidar_words(c); e += 64 * D) tile[e] = 1.0f;
+      for (int e = s * 64 + lane; e < lidar_words(c); e += 64 * P) tile[e] = 1.0f;
     }
   }
 
@@ -322,6 +332,13 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
     if (placed) { mx = w.x; my = w.y; mz = w.z; }
     if (reset && is_p) { mun = max_munition_of(c, s); lf = -c.cooldown_steps; fx = mx; fy = my; fz = mz; }
   }
+  if (s == 0 && __ballot(task != 0u) != 0ull) {   // the retired waves' share of Task.setup_round / on_reset: their invaders go back to WaitState
+    for (uint32_t m = inv_bits & ~live; m; m &= m - 1u) {
+      const int k2 = __ffs((int)m) - 1;
+      if (__ballot(valid && may_be_spawned(k2, (int)w_round)) != 0ull) continue;   // that wave stayed and does it itself (spawn_slot_at)
+      if (task != 0u) io.st(TE_D_NAV_STATE, k2, (uint32_t)TE_NAV_WAIT);
+    }
+  }
   const uint32_t armed_post = task != 0u ? snap_mask : A;   // after the spawn: the pursuers as they are (all armed on reset) + the round's invaders
   L(R.npos(0, s)) = __float_as_uint(mx); L(R.npos(1, s)) = __float_as_uint(my); L(R.npos(2, s)) = __float_as_uint(mz);
   if (o.term.lidar && term_b) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the terminal tiles has landed
@@ -373,11 +390,13 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
     }
   }
   // ---- what the next sub-step launch has to fly for this chunk (post-spawn flags): a wave walks the slots up to its own and writes its
-  // items; the last wave has walked them all and writes the chunk's masks
-  if (s >= 1) {
+  // items; the last pursuer wave walks them all and writes the chunk's masks
+  const int writer = P - 1;   // (always there; an invader wave may have retired)
+  if (s >= 1 || s == writer) {
     uint64_t dense = 0u, livem = 0u; int n = 0;
     uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
-    for (int k = 0; k <= s; ++k) {
+    const int k_last = s == writer ? D - 1 : s;
+    for (int k = 0; k <= k_last; ++k) {
       const bool a = valid && ((armed_post >> k) & 1u) != 0u;
       const unsigned long long b = __ballot(a);
       const int cnt = __popcll(b);
@@ -387,7 +406,7 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
       if (k == s && a) items[n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | (k << 8));
       n += cnt;
     }
-    if (s == D - 1 && lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = (uint32_t)n; p.live_mask[blockIdx.x] = livem; }
+    if (s == writer && lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = (uint32_t)n; p.live_mask[blockIdx.x] = livem; }
   }
   TE_WSTAMP(6, 0);
   TE_WSTAMP(7, 1);

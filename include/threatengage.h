@@ -385,7 +385,12 @@ int te_wingman_info(te_env* env, int32_t* wingman_info, void* stream);
  * call rewrites only the cells that change (the cells the previous observation patched go back to 1, the new ones are patched) instead of
  * streaming the whole background; the buffer ends up bit for bit as the dense path leaves it.  A different pointer (e.g. the slots of a
  * rollout buffer) takes the dense path for that call.  Terminal buffers are always dense.  on == 0 (the default): every call is dense.
- * The algorithmic bytes of such a step are the cells it touches, not the background: bench.py keeps the dense path as its headline. */
+ * The algorithmic bytes of such a step are the cells it touches, not the background: bench.py keeps the dense path as its headline.
+ * "The same buffer" is recognised by its ADDRESS alone: the caller must keep the allocation alive for as long as it passes it — a buffer
+ * that is freed and whose memory is handed to a NEW allocation at the same address (a caching allocator does that) would be taken for the old
+ * one and its background never written.  te_set_persistent_obs(env, 0) followed by (env, 1) forgets the remembered buffer: call it whenever
+ * the buffer's identity changes.  Under cfg.io_location == TE_IO_HOST the persistent buffer is the library's own staging (the caller's host
+ * array is filled from it every call); the terminal rows of done envs are compacted in a staging of their own. */
 int te_set_persistent_obs(te_env* env, int32_t on);
 
 /* Synthetic random-action generator of the throughput harness
