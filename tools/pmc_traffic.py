@@ -26,14 +26,14 @@ res = {"calibration": {"fetch_4B": f4, "fetch_16B": f16, "write_4B": w4, "write_
 fetch = load(os.path.join(out, "bench_FETCH_SIZE", "b_counter_collection.csv"))
 write = load(os.path.join(out, "bench_WRITE_SIZE", "b_counter_collection.csv"))
 for k in fetch:
-    if "substeps_kernel" in k or "engage_observe_kernel" in k or "engage_kernel" in k:
-        name = "substeps_kernel" if "substeps" in k else "engage_observe_kernel"   # engage_kernel<PM, IM> = its register-resident form
+    if "substeps_kernel" in k or "engage" in k:
+        name = "substeps_kernel" if "substeps" in k else "engage_observe_kernel"   # engage_slots_kernel / engage_kernel<PM, IM>: the forms of the engage/observe step
         fr = sum(fetch[k][-10:]) / 10 * 1024; wr = sum(write[k][-10:]) / 10 * 1024
         # both kernels read with 4 B/lane loads; K1 writes state with 4 B/lane stores + the LIDAR background with 16 B/lane
         # stores, K2 writes with 4 B/lane stores: apply the 4 B factors (the 16 B write factor is reported alongside)
-        res[name] = {"fetch_raw_bytes": fr, "write_raw_bytes": wr, "hbm_bytes_per_launch": fr * f4 + wr * w4,
+        res[name] = {"kernel": k, "fetch_raw_bytes": fr, "write_raw_bytes": wr, "hbm_bytes_per_launch": fr * f4 + wr * w4,
                      "fetch_bytes": fr * f4, "write_bytes": wr * w4}
-        print(name, {kk: round(vv / 1e6, 1) for kk, vv in res[name].items()}, "MB")
+        print(name, {kk: round(vv / 1e6, 1) for kk, vv in res[name].items() if kk != "kernel"}, "MB")
 os.makedirs("profiles", exist_ok=True)
 res["source"] = "tools/pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 20 --warmup 10 --headline-only`, averages of the last 10 launches"
 json.dump(res, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
