@@ -52,6 +52,9 @@ def _same_rollout(a, b, steps, seed=11, persistent=False, external=False):
 @pytest.mark.parametrize("task,n,over", [
     ("stage03", 8192, {}), ("stage03", 1000, {"seed": 5}), ("exp02", 4096, {}), ("exp04", 2048, {}), ("evaluation", 2048, {}),
     ("stage03", 2048, {"lidar_channels": 2}), ("stage03", 2048, {"motor_noise": 0, "quad_preset": 0}),
+    # the widest shape the slot waves serve: 4 pursuers (three behaviour-tree allies, the "first armed ally is skipped" rule) + 12 invader slots
+    # = 16 waves per workgroup, against engage_kernel<6, 12>; and the smallest shards
+    ("exp03", 2048, {"n_pursuers": 4, "n_invaders": 12, "n_rounds": 12, "max_step": 60}), ("stage03", 1, {"max_step": 30}), ("stage03", 63, {"max_step": 30}),
 ])
 def test_slot_waves_equal_the_one_wave_kernel_along_rollouts(monkeypatch, task, n, over):
     a, b = _pair(monkeypatch, task, n, **over)
