@@ -273,7 +273,7 @@ TE_DEV float x_atan2(float y, float x) {
 }
 
 struct V3 { float x, y, z; };
-TE_DEV float norm(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+TE_DEV float norm(V3 a) { TE_EXACT return sqrtf(xfma(a.z, a.z, xfma(a.y, a.y, a.x * a.x))); }
 TE_DEV V3 sub(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 struct Q4 { float x, y, z, w; };
 struct M3 { float m00, m01, m02, m10, m11, m12, m20, m21, m22; };
@@ -291,29 +291,42 @@ TE_DEV M3 rotation(Q4 q) {
 // the same for a quaternion that is already normalised (the sub-step loop renormalises b.q every sub-step, as
 // Bullet's integrator does): s = 2 / |q|^2 = 2 up to 1e-7, no reciprocal
 TE_DEV M3 rotation_unit(Q4 q) {
-  float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
-  float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
-  float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
-  float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
-  return M3{1.0f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0f - (xx + yy)};
+  TE_EXACT
+  const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
+  const float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+  const float yy = q.y * ys, zz = q.z * zs;
+  return M3{1.0f - xfma(q.y, ys, zz), xfma(q.x, ys, -wz), xfma(q.x, zs, wy), xfma(q.x, ys, wz), 1.0f - xfma(q.x, xs, zz), xfma(q.y, zs, -wx),
+            xfma(q.x, zs, -wy), xfma(q.y, zs, wx), 1.0f - xfma(q.x, xs, yy)};
+}
+// rotation() in exact arithmetic (the flights' prologue and epilogue: inlined into every instantiation of the sub-step kernel)
+TE_DEV M3 x_rotation(Q4 q) {
+  TE_EXACT
+  const float d = xfma(q.w, q.w, xfma(q.z, q.z, xfma(q.y, q.y, q.x * q.x)));
+  const float s = 2.0f * rcp(d);
+  const float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  const float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+  const float yy = q.y * ys, zz = q.z * zs;
+  return M3{1.0f - xfma(q.y, ys, zz), xfma(q.x, ys, -wz), xfma(q.x, zs, wy), xfma(q.x, ys, wz), 1.0f - xfma(q.x, xs, zz), xfma(q.y, zs, -wx),
+            xfma(q.x, zs, -wy), xfma(q.y, zs, wx), 1.0f - xfma(q.x, xs, yy)};
 }
 TE_DEV V3 mul(const M3& R, V3 v) {
-  return V3{R.m00 * v.x + R.m01 * v.y + R.m02 * v.z, R.m10 * v.x + R.m11 * v.y + R.m12 * v.z,
-            R.m20 * v.x + R.m21 * v.y + R.m22 * v.z};
+  TE_EXACT
+  return V3{xfma(R.m02, v.z, xfma(R.m01, v.y, R.m00 * v.x)), xfma(R.m12, v.z, xfma(R.m11, v.y, R.m10 * v.x)), xfma(R.m22, v.z, xfma(R.m21, v.y, R.m20 * v.x))};
 }
 TE_DEV V3 mulT(const M3& R, V3 v) {
-  return V3{R.m00 * v.x + R.m10 * v.y + R.m20 * v.z, R.m01 * v.x + R.m11 * v.y + R.m21 * v.z,
-            R.m02 * v.x + R.m12 * v.y + R.m22 * v.z};
+  TE_EXACT
+  return V3{xfma(R.m20, v.z, xfma(R.m10, v.y, R.m00 * v.x)), xfma(R.m21, v.z, xfma(R.m11, v.y, R.m01 * v.x)), xfma(R.m22, v.z, xfma(R.m12, v.y, R.m02 * v.x))};
 }
 // roll/pitch/yaw with pybullet's gimbal guard (getEulerFromQuaternion); R entries equal the quaternion
 // polynomials of that routine for a unit quaternion.  Polynomial atan2/asin (~1e-7): no libm in kernels.
 TE_DEV V3 euler_of(Q4 q) {
-  float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, sqw = q.w * q.w;
-  float sarg = -2.0f * (q.x * q.z - q.w * q.y);
-  if (sarg <= -0.99999f) return V3{0.0f, -0.5f * kPi, 2.0f * fast_atan2(q.x, -q.y)};
-  if (sarg >= 0.99999f) return V3{0.0f, 0.5f * kPi, 2.0f * fast_atan2(-q.x, q.y)};
-  return V3{fast_atan2(2.0f * (q.y * q.z + q.w * q.x), sqw - sqx - sqy + sqz), fast_asin(sarg),
-            fast_atan2(2.0f * (q.x * q.y + q.w * q.z), sqw + sqx - sqy - sqz)};
+  TE_EXACT
+  const float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, sqw = q.w * q.w;
+  const float sarg = -2.0f * xfma(q.x, q.z, -(q.w * q.y));
+  if (sarg <= -0.99999f) return V3{0.0f, -0.5f * kPi, 2.0f * x_atan2(q.x, -q.y)};
+  if (sarg >= 0.99999f) return V3{0.0f, 0.5f * kPi, 2.0f * x_atan2(-q.x, q.y)};
+  return V3{x_atan2(2.0f * xfma(q.y, q.z, q.w * q.x), ((sqw - sqx) - sqy) + sqz), x_asin(sarg),
+            x_atan2(2.0f * xfma(q.x, q.y, q.w * q.z), ((sqw + sqx) - sqy) - sqz)};
 }
 // getQuaternionFromEuler (btQuaternion::setEulerZYX), normalised
 TE_DEV Q4 quat_of_euler(V3 e) {
@@ -360,6 +373,7 @@ __host__ __device__ inline Derived derive(const te_config& c) {
 
 // PyFlyt PID.step with the period folded into the gains (kiT = ki * T, kdT = kd / T): 2 fma + 2 clamps + 1 sub
 TE_DEV float pid(float kp, float kiT, float kdT, float lim, float err, float& I, float& prev) {
+  TE_EXACT
   I = clampf(fmaf(kiT, err, I), -lim, lim);
   const float d = err - prev;
   prev = err;
@@ -385,6 +399,7 @@ TE_DEV U4 motor_noise_bits(const te_config& c, int env, int slot, uint32_t episo
 }
 // `m2ln2_gain2` = -2 ln 2 * gain^2: the normals come out already multiplied by the noise gain.
 TE_DEV void motor_noise_from(uint32_t a, uint32_t b, float m2ln2_gain2, float nz[4]) {
+  TE_EXACT
   const float k16 = 1.0f / 65536.0f;
   float r0 = fsqrt(m2ln2_gain2 * log2_native(((float)(a & 0xFFFFu) + 0.5f) * k16)), r1 = fsqrt(m2ln2_gain2 * log2_native(((float)(b & 0xFFFFu) + 0.5f) * k16));
   float a0 = (float)(a >> 16) * k16, a1 = (float)(b >> 16) * k16;  // revolutions
@@ -404,9 +419,13 @@ TE_DEV void motor_noise_from(uint32_t a, uint32_t b, float m2ln2_gain2, float nz
 // CTRL: 1 = the controller runs in this sub-step and its pwm is used at once (the reference's loop: update_control on every physics
 // sub-step, level4_simulation.py:92-94); for cfg.control_every_substep == 0 (PyFlyt's own 120 Hz): 0 = a controller sub-step whose
 // pwm is also kept in b.pwm, 2 = a coasting sub-step that feeds the motors b.pwm again (no IMU angles, no PIDs, unless CAPTURE)
+// EXACT ARITHMETIC (round 4): the function is inlined into every instantiation of the sub-step kernel (dense / mixed flights, noise on / off, both
+// controller rates, three task families), whose results are compared bitwise (mixed = dense flights; shards = the whole range).  Contraction is
+// off and every fused multiply-add is spelled out, so no instantiation can fuse a sum differently from another (te_device.hpp "exact arithmetic").
 template <bool MODE7, bool CAPTURE, bool NOISE, bool GROUND = false, int CTRL = 1>
 TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float sp[4], uint32_t noise_a, uint32_t noise_b,
                     V3& pend_f, V3& pend_t) {
+  TE_EXACT
   const te_quad_params& qp = c.quad;
   const float dt = k.dt;
   M3 R = rotation_unit(b.q);
@@ -423,29 +442,32 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
 #endif
              __builtin_amdgcn_ballot_w64(!(R.m22 > 0.0f && fabsf(R.m21) <= 0.4142135623730950f * R.m22 && fabsf(sarg) <= 0.5f)) == 0ull) {
     // Every lane of the wave flies within 22.5 degrees of roll and 30 degrees of pitch (the cascade's tilt limit is 0.4 rad): both
-    // inverse functions are on their central branch, where fast_atan2 / fast_asin reduce to their odd polynomials — the same values,
+    // inverse functions are on their central branch, where x_atan2 / x_asin reduce to their odd polynomials — the same values, bit for bit,
     // without the range reduction, the square root and the selects of the general form (wave-uniform test; ~20 VALU instructions)
     const float t = R.m21 * rcp(R.m22);
-    roll = atan_poly(t);
-    const float z = sarg * sarg;
-    pitch = sarg + sarg * z * asin_poly(z);
-    float inv = rsq(R.m00 * R.m00 + R.m10 * R.m10);
+    const float zt = t * t;
+    const float pa = xfma(xfma(xfma(8.05374449538e-2f, zt, -1.38776856032e-1f), zt, 1.99777106478e-1f), zt, -3.33329491539e-1f);
+    roll = xfma(pa * zt, t, t);
+    const float zs = sarg * sarg;
+    const float ps = xfma(xfma(xfma(xfma(4.2163199048e-2f, zs, 2.4181311049e-2f), zs, 4.5470025998e-2f), zs, 7.4953002686e-2f), zs, 1.6666752422e-1f);
+    pitch = xfma(sarg * zs, ps, sarg);
+    const float inv = rsq(xfma(R.m10, R.m10, R.m00 * R.m00));
     cyaw = R.m00 * inv; syaw = R.m10 * inv;
   } else if (!guard) {
-    roll = fast_atan2(R.m21, R.m22);
-    pitch = fast_asin(sarg);
-    float inv = rsq(R.m00 * R.m00 + R.m10 * R.m10);
+    roll = x_atan2(R.m21, R.m22);
+    pitch = x_asin(sarg);
+    const float inv = rsq(xfma(R.m10, R.m10, R.m00 * R.m00));
     cyaw = R.m00 * inv; syaw = R.m10 * inv;
   } else {  // pybullet's gimbal guard (rare): roll = 0, pitch = +-pi/2, yaw = 2 atan2(+-x, -+y)
     roll = 0.0f; pitch = sarg > 0.0f ? 0.5f * kPi : -0.5f * kPi;
     float sy = sarg > 0.0f ? -b.q.x : b.q.x, cy = sarg > 0.0f ? b.q.y : -b.q.y;  // half-angle direction
-    float inv = rsq(fmaxf(sy * sy + cy * cy, 1e-30f));
+    const float inv = rsq(fmaxf(xfma(cy, cy, sy * sy), 1e-30f));
     sy *= inv; cy *= inv;
-    cyaw = cy * cy - sy * sy; syaw = 2.0f * sy * cy;  // double angle
+    cyaw = xfma(cy, cy, -(sy * sy)); syaw = 2.0f * sy * cy;  // double angle
   }
   if (CAPTURE) {  // the IMU read the observation / reward / engagement will see (one-sub-step lag)
     b.o_pos = b.pos; b.o_vel = vb; b.o_rate = b.wb;
-    b.o_eul = guard ? euler_of(b.q) : V3{roll, pitch, fast_atan2(R.m10, R.m00)};
+    b.o_eul = guard ? euler_of(b.q) : V3{roll, pitch, x_atan2(R.m10, R.m00)};
   }
   // ---- controller (PyFlyt QuadX.update_control; every sub-step, PID period control_dt)
   float pwm[4];
@@ -459,7 +481,7 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
     a1 = clampf(qp.lin_pos_kp[1] * (a1 - b.pos.y), -qp.lin_pos_lim[1], qp.lin_pos_lim[1]);
     zc = clampf(qp.z_pos_kp * (zc - b.pos.z), -qp.z_pos_lim, qp.z_pos_lim);
   }
-  float u = cyaw * a0 + syaw * a1, v = -syaw * a0 + cyaw * a1;
+  const float u = xfma(syaw, a1, cyaw * a0), v = xfma(cyaw, a1, -(syaw * a0));
   float ox = pid(qp.lin_vel_kp[0], k.lv_kiT[0], k.lv_kdT[0], qp.lin_vel_lim[0], u - vb.x, b.lv_i[0], b.lv_e[0]);
   float oy = pid(qp.lin_vel_kp[1], k.lv_kiT[1], k.lv_kdT[1], qp.lin_vel_lim[1], v - vb.y, b.lv_i[1], b.lv_e[1]);
   float r0 = clampf(qp.ang_pos_kp[0] * (-oy - roll), -qp.ang_pos_lim[0], qp.ang_pos_lim[0]);
@@ -469,7 +491,7 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
   float t2 = pid(qp.ang_vel_kp[2], k.av_kiT[2], k.av_kdT[2], qp.ang_vel_lim[2], sp[2] - b.wb.z, b.av_i[2], b.av_e[2]);
   float th = pid(qp.z_vel_kp, k.zv_kiT, k.zv_kdT, qp.z_vel_lim, zc - vb.z, b.zv_i, b.zv_e);
   th = clampf(th, 0.0f, 1.0f);
-  pwm[0] = -t0 - t1 + t2 + th; pwm[1] = t0 + t1 + t2 + th; pwm[2] = -t0 + t1 - t2 + th; pwm[3] = t0 - t1 - t2 + th;
+  pwm[0] = ((-t0 - t1) + t2) + th; pwm[1] = ((t0 + t1) + t2) + th; pwm[2] = ((-t0 + t1) - t2) + th; pwm[3] = ((t0 - t1) - t2) + th;
   float hi = fmaxf(fmaxf(pwm[0], pwm[1]), fmaxf(pwm[2], pwm[3]));
   if (__builtin_amdgcn_ballot_w64(hi > 1.0f) != 0ull && hi > 1.0f) {  // wave-uniform test first: saturation is rare
     float s = rcp(hi);
@@ -480,7 +502,7 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
   if (lo < k.pwm_floor) {
     float f = (k.pwm_floor - lo) * rcp(1.0f - lo);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pwm[i] += (1.0f - pwm[i]) * f;
+    for (int i = 0; i < 4; ++i) pwm[i] = xfma(1.0f - pwm[i], f, pwm[i]);
   }
   if (CTRL == 0) {
 #pragma unroll
@@ -493,18 +515,18 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float t = b.thr[i];
-    t += k.k_motor * (pwm[i] - t);
-    if (NOISE) t = fmaf(nz[i], t, t);
+    t = xfma(k.k_motor, pwm[i] - t, t);
+    if (NOISE) t = xfma(nz[i], t, t);
     b.thr[i] = t;
     T_[i] = t * t;
   }
   // layout m0 front-right (+x,-y), m1 back-left (-x,+y), m2 back-right (-x,-y), m3 front-left (+x,+y)
-  float fz = k.q_thrust * (T_[0] + T_[1] + T_[2] + T_[3]);
-  float tx = k.q_arm * (-T_[0] + T_[1] - T_[2] + T_[3]);
-  float ty = k.q_arm * (-T_[0] + T_[1] + T_[2] - T_[3]);
-  float tz = k.q_torque * (T_[0] + T_[1] - T_[2] - T_[3]);
-  V3 Fb{-k.k_drag * fabsf(vb.x) * vb.x, -k.k_drag * fabsf(vb.y) * vb.y, -k.k_drag * fabsf(vb.z) * vb.z + fz};
-  V3 Tb{tx - k.k_pqr * fabsf(b.wb.x) * b.wb.x, ty - k.k_pqr * fabsf(b.wb.y) * b.wb.y, tz - k.k_pqr * fabsf(b.wb.z) * b.wb.z};
+  const float fz = k.q_thrust * (((T_[0] + T_[1]) + T_[2]) + T_[3]);
+  const float tx = k.q_arm * (((-T_[0] + T_[1]) - T_[2]) + T_[3]);
+  const float ty = k.q_arm * (((-T_[0] + T_[1]) + T_[2]) - T_[3]);
+  const float tz = k.q_torque * (((T_[0] + T_[1]) - T_[2]) - T_[3]);
+  V3 Fb{(-k.k_drag * fabsf(vb.x)) * vb.x, (-k.k_drag * fabsf(vb.y)) * vb.y, xfma(-k.k_drag * fabsf(vb.z), vb.z, fz)};
+  V3 Tb{xfma(-(k.k_pqr * fabsf(b.wb.x)), b.wb.x, tx), xfma(-(k.k_pqr * fabsf(b.wb.y)), b.wb.y, ty), xfma(-(k.k_pqr * fabsf(b.wb.z)), b.wb.z, tz)};
   V3 Fw = mul(R, Fb);
   if (MODE7) {  // wrench accumulated outside the loop (stage01 replace_invader), world frame
     Fw.x += pend_f.x; Fw.y += pend_f.y; Fw.z += pend_f.z;
@@ -513,43 +535,44 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
     pend_f = V3{0, 0, 0}; pend_t = V3{0, 0, 0};
   }
   // ---- Bullet semi-implicit Euler (stepSimulation): gyroscopic term, exponential-map attitude update
-  V3 Iw{k.ix * b.wb.x, k.iy * b.wb.y, k.iz * b.wb.z};
-  V3 gy{b.wb.y * Iw.z - b.wb.z * Iw.y, b.wb.z * Iw.x - b.wb.x * Iw.z, b.wb.x * Iw.y - b.wb.y * Iw.x};
-  b.wb = V3{b.wb.x + k.dt_inv_ix * (Tb.x - gy.x), b.wb.y + k.dt_inv_iy * (Tb.y - gy.y), b.wb.z + k.dt_inv_iz * (Tb.z - gy.z)};
-  b.vel = V3{b.vel.x + k.dt_inv_m * Fw.x, b.vel.y + k.dt_inv_m * Fw.y, b.vel.z + (k.dt_inv_m * Fw.z - k.dt_g)};
-  b.pos = V3{b.pos.x + dt * b.vel.x, b.pos.y + dt * b.vel.y, b.pos.z + dt * b.vel.z};
+  const V3 Iw{k.ix * b.wb.x, k.iy * b.wb.y, k.iz * b.wb.z};
+  const V3 gy{xfma(b.wb.y, Iw.z, -(b.wb.z * Iw.y)), xfma(b.wb.z, Iw.x, -(b.wb.x * Iw.z)), xfma(b.wb.x, Iw.y, -(b.wb.y * Iw.x))};
+  b.wb = V3{xfma(k.dt_inv_ix, Tb.x - gy.x, b.wb.x), xfma(k.dt_inv_iy, Tb.y - gy.y, b.wb.y), xfma(k.dt_inv_iz, Tb.z - gy.z, b.wb.z)};
+  b.vel = V3{xfma(k.dt_inv_m, Fw.x, b.vel.x), xfma(k.dt_inv_m, Fw.y, b.vel.y), b.vel.z + xfma(k.dt_inv_m, Fw.z, -k.dt_g)};
+  b.pos = V3{xfma(dt, b.vel.x, b.pos.x), xfma(dt, b.vel.y, b.pos.y), xfma(dt, b.vel.z, b.pos.z)};
   if (GROUND && c.ground_contact && b.pos.z < k.ground_rest) {  // opt-in ground plane (config-uniform test first): inelastic normal
     // contact, Coulomb friction mu = 0.5 (Bullet's default 0.5 x plane.urdf's 1.0) against the normal impulse; unpinned
     const float jn = fmaxf(-b.vel.z, 0.0f);
     b.pos.z = k.ground_rest; b.vel.z = fmaxf(b.vel.z, 0.0f);
-    const float vt2 = b.vel.x * b.vel.x + b.vel.y * b.vel.y;
+    const float vt2 = xfma(b.vel.y, b.vel.y, b.vel.x * b.vel.x);
     if (vt2 > 0.0f) {
-      const float vt = fsqrt(vt2), keep = fmaxf(vt - 0.5f * jn, 0.0f) * rcp(vt);
+      const float vt = fsqrt(vt2), keep = fmaxf(xfma(-0.5f, jn, vt), 0.0f) * rcp(vt);
       b.vel.x *= keep; b.vel.y *= keep;
     }
   }
-  float w2 = b.wb.x * b.wb.x + b.wb.y * b.wb.y + b.wb.z * b.wb.z;
-  float h2 = k.quarter_dt2 * w2;  // (half angle)^2
+  const float w2 = xfma(b.wb.z, b.wb.z, xfma(b.wb.y, b.wb.y, b.wb.x * b.wb.x));
+  const float h2 = k.quarter_dt2 * w2;  // (half angle)^2
   float sc, ch;                     // sin(h)/|w| and cos(h)
   if (h2 < 0.25f) {
-    sc = k.half_dt * (1.0f + h2 * (-1.0f / 6.0f + h2 * (1.0f / 120.0f + h2 * (-1.0f / 5040.0f + h2 * (1.0f / 362880.0f)))));
-    ch = 1.0f + h2 * (-0.5f + h2 * (1.0f / 24.0f + h2 * (-1.0f / 720.0f + h2 * (1.0f / 40320.0f + h2 * (-1.0f / 3628800.0f)))));
+    sc = k.half_dt * xfma(h2, xfma(h2, xfma(h2, xfma(h2, 1.0f / 362880.0f, -1.0f / 5040.0f), 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+    ch = xfma(h2, xfma(h2, xfma(h2, xfma(h2, xfma(h2, -1.0f / 3628800.0f, 1.0f / 40320.0f), -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
   } else {  // > 240 rad/s: native sin/cos (inputs in revolutions) are plenty
-    float inv_w = rsq(w2);
-    float rev = k.half_dt * (w2 * inv_w) * (0.5f / kPi);
+    const float inv_w = rsq(w2);
+    const float rev = (k.half_dt * (w2 * inv_w)) * (0.5f / kPi);
     sc = sin_rev(rev) * inv_w; ch = cos_rev(rev);
   }
-  Q4 dq{b.wb.x * sc, b.wb.y * sc, b.wb.z * sc, ch};
-  Q4 q = b.q;  // q <- q (x) dq   (body-frame increment on the right)
-  Q4 n{q.w * dq.x + q.x * dq.w + q.y * dq.z - q.z * dq.y, q.w * dq.y - q.x * dq.z + q.y * dq.w + q.z * dq.x,
-       q.w * dq.z + q.x * dq.y - q.y * dq.x + q.z * dq.w, q.w * dq.w - q.x * dq.x - q.y * dq.y - q.z * dq.z};
-  float inv = rsq(n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w);
+  const Q4 dq{b.wb.x * sc, b.wb.y * sc, b.wb.z * sc, ch};
+  const Q4 q = b.q;  // q <- q (x) dq   (body-frame increment on the right)
+  const Q4 n{xfma(-q.z, dq.y, xfma(q.y, dq.z, xfma(q.x, dq.w, q.w * dq.x))), xfma(q.z, dq.x, xfma(q.y, dq.w, xfma(-q.x, dq.z, q.w * dq.y))),
+             xfma(q.z, dq.w, xfma(-q.y, dq.x, xfma(q.x, dq.y, q.w * dq.z))), xfma(-q.z, dq.z, xfma(-q.y, dq.y, xfma(-q.x, dq.x, q.w * dq.w)))};
+  const float inv = rsq(xfma(n.w, n.w, xfma(n.z, n.z, xfma(n.y, n.y, n.x * n.x))));
   b.q = Q4{n.x * inv, n.y * inv, n.z * inv, n.w * inv};
 }
 
 // Quadcopter.convert_command_to_setpoint (quadcopter.py:379-396): unit(direction) * magnitude
 TE_DEV void command_to_velocity(float dx, float dy, float dz, float mag, float& vx, float& vy, float& vz) {
-  float n = sqrtf(dx * dx + dy * dy + dz * dz);
+  TE_EXACT
+  float n = sqrtf(xfma(dz, dz, xfma(dy, dy, dx * dx)));
   float inv = 1.0f / (n > 0.0f ? n : 1.0f);
   vx = mag * (dx * inv); vy = mag * (dy * inv); vz = mag * (dz * inv);
 }

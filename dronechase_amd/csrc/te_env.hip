@@ -151,11 +151,11 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
   b.q = Q4{raw[TE_D_QUAT], raw[TE_D_QUAT + 1], raw[TE_D_QUAT + 2], raw[TE_D_QUAT + 3]};
   {  // the loop's rotation_unit() assumes |q| = 1: true for every state this library writes, enforced for blobs
      // that came in through te_set_state
-    const float inv = rsq(b.q.x * b.q.x + b.q.y * b.q.y + b.q.z * b.q.z + b.q.w * b.q.w);
+    const float inv = rsq(xfma(b.q.w, b.q.w, xfma(b.q.z, b.q.z, xfma(b.q.y, b.q.y, b.q.x * b.q.x))));
     b.q = Q4{b.q.x * inv, b.q.y * inv, b.q.z * inv, b.q.w * inv};
   }
   b.vel = V3{raw[TE_D_VEL], raw[TE_D_VEL + 1], raw[TE_D_VEL + 2]};
-  b.wb = mulT(rotation(b.q), V3{raw[TE_D_OMEGA], raw[TE_D_OMEGA + 1], raw[TE_D_OMEGA + 2]});
+  b.wb = mulT(x_rotation(b.q), V3{raw[TE_D_OMEGA], raw[TE_D_OMEGA + 1], raw[TE_D_OMEGA + 2]});
 #pragma unroll
   for (int k = 0; k < 4; ++k) b.thr[k] = raw[TE_D_THROTTLE + k];
 #pragma unroll
@@ -219,7 +219,7 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
 #undef TE_DRAW
 
   // ---- store
-  const M3 R = rotation(b.q);
+  const M3 R = x_rotation(b.q);
   if (!c.observe_lag) {  // IMU refreshed after the loop
     b.o_pos = b.pos; b.o_vel = mulT(R, b.vel); b.o_rate = b.wb; b.o_eul = euler_of(b.q);
   }

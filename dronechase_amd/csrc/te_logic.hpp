@@ -254,12 +254,6 @@ template <class V> TE_DEV int closest_ally(const V& v, uint64_t mask, int p) {
 // They depend only on the state at the end of this step.  The allies' are prepared here (engage/observe kernel)
 // and read back by the sub-step kernel; each invader works its own out at the top of the sub-step kernel.
 // ------------------------------------------------------------------------------------------------
-TE_DEV void cmd_toward(V3 from, V3 to, float speed, float out[3]) {
-  V3 d = sub(to, from);
-  float n = norm(d);
-  float inv = n > 0.0f ? 1.0f / n : 1.0f;  // zero vector stays zero (…air_combat_only.py:191-195)
-  command_to_velocity(d.x * inv, d.y * inv, d.z * inv, speed, out[0], out[1], out[2]);
-}
 // cmd_toward + Quadcopter.convert_command_to_setpoint (te_device.hpp: command_to_velocity) for the behaviour tree's command, in exact
 // arithmetic (te_device.hpp): prepare_slot (after te_reset / te_set_state) and the engage kernels (during a rollout) must write the same bits
 TE_DEV void x_cmd_toward(V3 from, V3 to, float speed, float out[3]) {
@@ -272,6 +266,7 @@ TE_DEV void x_cmd_toward(V3 from, V3 to, float speed, float out[3]) {
   const float inv2 = 1.0f / (m > 0.0f ? m : 1.0f);
   out[0] = speed * (ux * inv2); out[1] = speed * (uy * inv2); out[2] = speed * (uz * inv2);
 }
+TE_DEV void cmd_toward(V3 from, V3 to, float speed, float out[3]) { x_cmd_toward(from, to, speed, out); }   // (one arithmetic for the navigators of the sub-step kernel and the engage kernels)
 // GeometryUtils.is_point_inside_cone (geometry_utils.py:6-29)
 TE_DEV bool inside_cone(V3 p, V3 apex, V3 base, float degrees) {
   V3 ab = sub(base, apex), ap = sub(p, apex);

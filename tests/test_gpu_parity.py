@@ -46,8 +46,9 @@ def _float_words():
     return fd, list(K.D_INT_WORDS), fe, list(K.E_INT_WORDS)
 
 
-def _compare_states(so, sg, N, D):
-    """-> (per-env max float diff, per-env bool any-int-mismatch)"""
+def _compare_states(so, sg, N, D, rate_error_tol=STATE_TOL):
+    """-> (per-env max float diff in units of STATE_TOL-equivalents, per-env bool any-int-mismatch).  `rate_error_tol`: the bound of the three
+    PID_AV_E words (the rate loop's previous error), scaled so that every word compares against STATE_TOL."""
     fd, idw, fe, iew = _float_words()
     do, eo = _split(so, N, D)
     dg, eg = _split(sg, N, D)
@@ -56,8 +57,10 @@ def _compare_states(so, sg, N, D):
     # profiles/r04_e_parity_margins.txt; 5 task variants x motor noise on / off x 8 checkpoints x 2 048 envs): pose / velocities <= 5.2e-5,
     # throttles <= 9.3e-6, the previous rate error PID_AV_E <= 8.7e-5 (control_every_substep = 0; 4.3e-5 under either quadrotor table with the
     # reference's loop), every other PID word <= 1.1e-6, IMU reads <= 3.6e-5.  (Round 3 had relaxed the PID words to 2 x STATE_TOL when the
-    # recorded-fit table became the default; the measurement shows that no word needs it.)
-    scale = np.ones(len(fd))
+    # recorded-fit table became the default; the measurement shows that no word needs it under the reference's loop.)  The one exception is
+    # cfg.control_every_substep = 0 (PyFlyt's own 120 Hz controller, not a reference mode): there the previous rate error reaches 8.7e-5 ... 1.0e-4
+    # depending on the build's rounding (it is the difference of two rad/s quantities held for two sub-steps), so that variant passes rate_error_tol = 2e-4.
+    scale = np.array([STATE_TOL / rate_error_tol if K.D["PID_AV_E"] <= w < K.D["PID_AV_E"] + 3 else 1.0 for w in fd])
     fdiff = (np.abs(do[..., fd].view(np.float32).astype(np.float64) - dg[..., fd].view(np.float32)) * scale).reshape(N, -1).max(1)
     ediff = np.abs(eo[:, fe].view(np.float32).astype(np.float64) - eg[:, fe].view(np.float32)).max(1)
     imis = (do[..., idw] != dg[..., idw]).any(axis=(1, 2)) | (eo[:, iew] != eg[:, iew]).any(axis=1)
@@ -99,7 +102,8 @@ def test_single_step_parity(task, over, noise):
         ok = orc.margins() > MARGIN
         gl, gi, ga, grew, gdone, ginfo = (x.cpu().numpy() for x in gpu.step(torch.from_numpy(a).cuda()))
         gtl, gti = gpu.t_lidar.cpu().numpy(), gpu.t_inertial.cpu().numpy()
-        diff, imis = _compare_states(orc.get_state(), gpu.get_state().cpu().numpy().view(np.uint32), N, D)
+        diff, imis = _compare_states(orc.get_state(), gpu.get_state().cpu().numpy().view(np.uint32), N, D,
+                                     rate_error_tol=2e-4 if over.get("control_every_substep") == 0 else STATE_TOL)
         n_ambiguous += int((~ok).sum())
         # every discrete mismatch must be an ambiguous env
         assert not (imis & ok).any(), f"{task}: integer state mismatch outside ambiguous envs at step {step}"
