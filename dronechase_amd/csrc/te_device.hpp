@@ -422,12 +422,17 @@ TE_DEV void motor_noise_from(uint32_t a, uint32_t b, float m2ln2_gain2, float nz
 // EXACT ARITHMETIC (round 4): the function is inlined into every instantiation of the sub-step kernel (dense / mixed flights, noise on / off, both
 // controller rates, three task families), whose results are compared bitwise (mixed = dense flights; shards = the whole range).  Contraction is
 // off and every fused multiply-add is spelled out, so no instantiation can fuse a sum differently from another (te_device.hpp "exact arithmetic").
-template <bool MODE7, bool CAPTURE, bool NOISE, bool GROUND = false, int CTRL = 1>
+// HELP (small shards, te_env.hip: substeps_kernel<..., HELP>): the four normals of this sub-step come out of LDS, where the flight's sibling
+// wave has left them (`nz_row`: this lane's 16 bytes of the sub-step's row) — the same motor_noise_bits / motor_noise_from values, computed by
+// another wave.  The row is requested at the top of the sub-step and used at the motors; fly() has made sure that it is published.
+template <bool MODE7, bool CAPTURE, bool NOISE, bool GROUND = false, int CTRL = 1, bool HELP = false>
 TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float sp[4], uint32_t noise_a, uint32_t noise_b,
-                    V3& pend_f, V3& pend_t) {
+                    V3& pend_f, V3& pend_t, const volatile float4* nz_row = nullptr) {
   TE_EXACT
   const te_quad_params& qp = c.quad;
   const float dt = k.dt;
+  float nzx = 0.0f, nzy = 0.0f, nzz = 0.0f, nzw = 0.0f;
+  if (NOISE && HELP) { nzx = nz_row->x; nzy = nz_row->y; nzz = nz_row->z; nzw = nz_row->w; }
   M3 R = rotation_unit(b.q);
   // ---- IMU (imu.py:27-41)
   V3 vb = mulT(R, b.vel);
@@ -511,7 +516,8 @@ TE_DEV void substep(const te_config& c, const Derived& k, Body& b, const float s
   }
   // ---- motors (first-order lag, multiplicative noise, thrust/torque ~ rpm^2) + drag
   float T_[4], nz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (NOISE) motor_noise_from(noise_a, noise_b, k.noise_m2ln2, nz);  // nz = noise_ratio * N(0, 1)
+  if (NOISE && HELP) { nz[0] = nzx; nz[1] = nzy; nz[2] = nzz; nz[3] = nzw; }
+  else if (NOISE) motor_noise_from(noise_a, noise_b, k.noise_m2ln2, nz);  // nz = noise_ratio * N(0, 1)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float t = b.thr[i];

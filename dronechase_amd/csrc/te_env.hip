@@ -53,6 +53,14 @@ namespace te {
 #ifndef TE_K1_BLOCK
 #define TE_K1_BLOCK 64
 #endif
+// te_create: (env, slot) pairs up to which the sub-step launch carries noise-helper waves (TE_K1_HELP=0 / 1 overrides).  The helper pays while the
+// launch has fewer flight waves than the chip has SIMDs (- 1.1 ... 2.0 us up to ~0.9 flights per SIMD, a tie at 1.3, + 3.5 us at 1.75 and above:
+// profiles/r04_m_ab_noise_helper_v2.txt); te_create cannot know how many drones will be armed, so the default admits only shards on which EVERY slot
+// armed is at most 1.5 flight waves per SIMD, where the helper roughly breaks even: n_envs x D <= 1.5 x 64 x 1 024 (stage01 up to 32 768 envs, stage03
+// up to 8 936: the metric's 8-GPU shard, which flies 0.4-0.6 flights per SIMD in a random-action rollout).  A decision per launch from
+// the flight plan was measured too (both waves of a block estimating the load from their chunk's plan): carrying both noise paths in one kernel cost
+// the helped flights their gain (33.0 -> 32.8 us at 8 192 envs instead of 31.6) and the declined ones 7 us.
+constexpr long long kHelpMaxPairs = 98304;
 #ifdef TE_K1_WAVES
 #define TE_K1_ATTR __attribute__((amdgpu_waves_per_eu(TE_K1_WAVES, TE_K1_WAVES)))
 #else
@@ -82,8 +90,8 @@ struct NavView {
 // the chunk's sparsely armed slots (Params::mixed_items), so `slot` is a per-lane value: the buffer addressing
 // (SlotLane: per-lane byte offset + scalar plane offset) is the same for both.
 // CES = cfg.control_every_substep (the reference's 240 Hz controller calls); false = PyFlyt-native 120 Hz
-template <int FAMILY, bool NOISE, bool MIXED, bool CES = true>
-TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, int env, bool valid) {
+template <int FAMILY, bool NOISE, bool MIXED, bool CES = true, bool HELP = false>
+TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, int env, bool valid, const float* nzbuf = nullptr, const volatile int* ready = nullptr) {
   const int D = p.D;
   const SlotLane P(p.dstate, p.estate, (uint32_t)D, (uint32_t)p.Npad, (uint32_t)slot, (uint32_t)env,
                    (uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)D * (uint32_t)p.Npad, (uint32_t)TE_ENV_WORDS * (uint32_t)p.Npad);
@@ -176,8 +184,13 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
   // MIXED: (env, slot) ride through the loop in ONE register and are unpacked at each draw (a per-lane slot next to
   // env would cost the kernel its 72nd VGPR, i.e. a wave per SIMD); te_create caps n_envs per te_env below 2^24
   const uint32_t env_slot = (uint32_t)env | ((uint32_t)slot << 24);
+  // HELP: rows published by the sibling wave so far, as last read (it runs ahead after the first sub-steps: a handful of polls per flight)
+  int seen = 0;
 #define TE_DRAW(s_)                                                                   \
-  if (NOISE) {                                                                        \
+  if (NOISE && HELP) {                                                                \
+    while (seen <= (s_)) { seen = __builtin_amdgcn_readfirstlane(*ready); if (seen <= (s_)) __builtin_amdgcn_s_sleep(1); }   \
+  }                                                                                   \
+  if (NOISE && !HELP) {                                                               \
     if (((s_) & 1) == 0) {                                                            \
       uint32_t es_ = env_slot;                                                        \
       if (MIXED) asm volatile("" : "+v"(es_));                                        \
@@ -190,32 +203,34 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
 #pragma unroll
     for (int i = 0; i < 4; ++i) b.pwm[i] = 0.0f;   // sub-step 0 is always a controller sub-step
   }
+#define NZROW(i_) (HELP ? reinterpret_cast<const volatile float4*>(nzbuf) + ((size_t)(i_) * 64 + (threadIdx.x & 63)) : nullptr)
   for (int s = 0; s < n_plain; ++s) {
     TE_DRAW(s)
     if (CES) {
-      if (mode7) substep<true, false, NOISE>(c, kd, b, sp, na, nb, pf, pt);  // wave-uniform: slot is per wave
-      else substep<false, false, NOISE, kGround>(c, kd, b, sp, na, nb, pf, pt);
+      if (mode7) substep<true, false, NOISE, false, 1, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(s));  // wave-uniform: slot is per wave
+      else substep<false, false, NOISE, kGround, 1, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(s));
     } else if (s % kd.ctrl_ratio == 0) {   // wave-uniform
-      if (mode7) substep<true, false, NOISE, false, 0>(c, kd, b, sp, na, nb, pf, pt);
-      else substep<false, false, NOISE, kGround, 0>(c, kd, b, sp, na, nb, pf, pt);
+      if (mode7) substep<true, false, NOISE, false, 0, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(s));
+      else substep<false, false, NOISE, kGround, 0, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(s));
     } else {
-      if (mode7) substep<true, false, NOISE, false, 2>(c, kd, b, sp, na, nb, pf, pt);
-      else substep<false, false, NOISE, kGround, 2>(c, kd, b, sp, na, nb, pf, pt);
+      if (mode7) substep<true, false, NOISE, false, 2, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(s));
+      else substep<false, false, NOISE, kGround, 2, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(s));
     }
   }
   if (c.observe_lag) {
     TE_DRAW(S - 1)
     if (CES) {
-      if (mode7) substep<true, true, NOISE>(c, kd, b, sp, na, nb, pf, pt);
-      else substep<false, true, NOISE, kGround>(c, kd, b, sp, na, nb, pf, pt);
+      if (mode7) substep<true, true, NOISE, false, 1, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(S - 1));
+      else substep<false, true, NOISE, kGround, 1, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(S - 1));
     } else if ((S - 1) % kd.ctrl_ratio == 0) {
-      if (mode7) substep<true, true, NOISE, false, 0>(c, kd, b, sp, na, nb, pf, pt);
-      else substep<false, true, NOISE, kGround, 0>(c, kd, b, sp, na, nb, pf, pt);
+      if (mode7) substep<true, true, NOISE, false, 0, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(S - 1));
+      else substep<false, true, NOISE, kGround, 0, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(S - 1));
     } else {
-      if (mode7) substep<true, true, NOISE, false, 2>(c, kd, b, sp, na, nb, pf, pt);
-      else substep<false, true, NOISE, kGround, 2>(c, kd, b, sp, na, nb, pf, pt);
+      if (mode7) substep<true, true, NOISE, false, 2, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(S - 1));
+      else substep<false, true, NOISE, kGround, 2, HELP>(c, kd, b, sp, na, nb, pf, pt, NZROW(S - 1));
     }
   }
+#undef NZROW
 #undef TE_DRAW
 
   // ---- store
@@ -265,15 +280,49 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
 #define TE_K1_END(kind) do {} while (0)
 #endif
 
-template <int FAMILY, bool NOISE, bool FILL, bool CES = true>
-__global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params p, const float* __restrict__ actions, FillJob fill) {
+// HELP: the sibling wave of a flight (small shards: fewer flights than SIMDs, every flight one lone wave).  The motor noise is the one part of a
+// sub-step that does not depend on the drone's state — Philox4x32-7 on (env, slot, episode, step, sub-step) + Box-Muller: 19 % of a lone flight's
+// time (noise off: 21.3 -> 17.5 us at 8 192 envs) — so this wave computes it for all sub-steps, two per Philox call like the flight would, and
+// publishes row after row in LDS: nzbuf[sub-step][lane] = four normals, *ready = rows published.  Same functions, same operands, exact arithmetic:
+// the flight flies on the same bits (tests/test_gpu_noise_helper.py).
+template <int FAMILY>
+TE_DEV void noise_help(const Params& p, int slot, int env, bool valid, float* nzbuf, volatile int* ready) {
+  const te_config& c = p.cfg;
+  const int lane = threadIdx.x & 63;
+  const SlotLane P(p.dstate, p.estate, (uint32_t)p.D, (uint32_t)p.Npad, (uint32_t)slot, (uint32_t)env,
+                   (uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)p.D * (uint32_t)p.Npad, (uint32_t)TE_ENV_WORDS * (uint32_t)p.Npad);
+  const int armed = P.li(TE_D_ARMED);
+  const uint32_t episode = (uint32_t)P.lei(TE_E_EPISODE);
+  const uint32_t step_index = (uint32_t)P.lei(TE_E_STEP) + (FAMILY == FAM_STAGE01 ? 1u : 0u);
+  if (__ballot(valid && armed != 0) == 0ull) return;   // the flight has nothing armed either and retires without asking
+  const int S = c.substeps;
+  for (int s = 0; s < S; s += 2) {
+    const U4 bits = motor_noise_bits(c, env, slot, episode, step_index, s);
+    float nz[4];
+    motor_noise_from(bits.x, bits.y, p.kd.noise_m2ln2, nz);
+    *reinterpret_cast<float4*>(nzbuf + ((size_t)s * 64 + lane) * 4) = make_float4(nz[0], nz[1], nz[2], nz[3]);
+    if (s + 1 < S) {
+      motor_noise_from(bits.z, bits.w, p.kd.noise_m2ln2, nz);
+      *reinterpret_cast<float4*>(nzbuf + ((size_t)(s + 1) * 64 + lane) * 4) = make_float4(nz[0], nz[1], nz[2], nz[3]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *ready = min(s + 2, S);
+  }
+}
+
+template <int FAMILY, bool NOISE, bool FILL, bool CES = true, bool HELP = false>
+__global__ __launch_bounds__(HELP ? 128 : TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params p, const float* __restrict__ actions, FillJob fill) {
   TE_K1_BEGIN
-  int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (unsigned)TE_K1_BLOCK + threadIdx.x) >> 6));
+  extern __shared__ float k1_lds[];   // HELP: [cfg.substeps][64][4] normals, then the `ready` word
+  int wave = HELP ? (int)blockIdx.x : __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (unsigned)TE_K1_BLOCK + threadIdx.x) >> 6));
+  const int role = HELP ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // 0 = the flight / fill wave, 1 = its noise helper
+  volatile int* ready = reinterpret_cast<volatile int*>(k1_lds + (HELP ? (size_t)p.cfg.substeps * 256 : 0));
   const int lane = threadIdx.x & 63;
   const int D = p.D;
   const int nchunks = p.Npad >> 6;
   float4* fill_dst = reinterpret_cast<float4*>(fill.lidar);
   if (FILL) {
+    if (HELP && role == 1 && wave < (int)fill.n_fill_waves) return;   // fill / erase blocks have no use for a helper
     if (wave < (int)fill.n_fill_waves && fill.mode == 3) {  // ---- erase wave (persistent observation)
       const uint32_t nch = fill.npad >> 6;
       const uint32_t list = (uint32_t)wave / nch, env = ((uint32_t)wave - list * nch) * 64u + (uint32_t)lane;
@@ -327,7 +376,12 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
     const int i = m * 64 + lane;
     const bool valid = i < count;
     const uint32_t item = valid ? (uint32_t)p.mixed_items[(size_t)chunk * kMixedCap + i] : 0u;
-    fly<FAMILY, NOISE, true, CES>(p, actions, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid);
+    if (HELP) {
+      if (role == 1 && lane == 0) *ready = 0;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (role == 1) { noise_help<FAMILY>(p, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid, k1_lds, ready); return; }
+    }
+    fly<FAMILY, NOISE, true, CES, HELP>(p, actions, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid, k1_lds, ready);
     TE_K1_END(3);
     return;
   }
@@ -341,7 +395,12 @@ __global__ __launch_bounds__(TE_K1_BLOCK) TE_K1_ATTR void substeps_kernel(Params
   const uint32_t chunk_mask = __builtin_amdgcn_readfirstlane(sm32[2 * chunk + (slot >> 5)]);   // the 32-bit half that holds this slot's bit
   if (!((chunk_mask >> (slot & 31)) & 1u)) { TE_K1_END(0); return; }
   const int env = chunk * 64 + lane;  // planes are padded to Npad: lanes beyond N still read in bounds
-  fly<FAMILY, NOISE, false, CES>(p, actions, slot, env, env < p.N);
+  if (HELP) {
+    if (role == 1 && lane == 0) *ready = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (role == 1) { noise_help<FAMILY>(p, slot, env, env < p.N, k1_lds, ready); return; }
+  }
+  fly<FAMILY, NOISE, false, CES, HELP>(p, actions, slot, env, env < p.N, k1_lds, ready);
   TE_K1_END(2);
 }
 
@@ -836,6 +895,7 @@ struct te_env {
   size_t dbg_words = 0;       // diagnostic builds: length of p.dbg
   int engage_regs = 0;         // 1 = engage_kernel<2, 9>, 2 = engage_kernel<6, 12> (level4 family), 3 = engage_stage02_kernel<2, 8>, 4 = engage_stage01_kernel (te_engage.hpp: the env in registers, one wave per
                                // chunk); 0 = engage_observe_kernel (LDS phases): other shapes, stage01 / stage02, TE_ENGAGE=lds
+  int k1_help = 0;             // 1 = substeps_kernel<..., HELP>: a noise-helper wave next to every flight (small shards; TE_K1_HELP=0/1)
   int engage_slots = 0;        // 1 = engage_slots_kernel (te_engage_slots.hpp: one wave per (chunk, slot)) instead of engage_kernel: small shards, TE_ENGAGE=slots
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
   float* zero_actions = nullptr;     // te_step_students: the [N,4] action batch nobody reads (every pursuer is scripted)
@@ -1006,6 +1066,9 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   if (cfg->drone_contact && !(e->engage_regs == 1 || e->engage_regs == 2))
     return bail("te_create: cfg.drone_contact is built into engage_kernel: the level4 task family with P <= 6 and P + I <= 18");
   e->p.dense_min = kDenseMin;
+  // noise-helper waves (substeps_kernel<..., HELP>): worth their issue slots only while SIMDs idle, i.e. on small shards
+  e->k1_help = (cfg->motor_noise && (long long)cfg->n_envs * D <= kHelpMaxPairs && cfg->substeps >= 2 && cfg->substeps <= 48) ? 1 : 0;
+  if (const char* v = getenv("TE_K1_HELP")) e->k1_help = (atoi(v) != 0 && cfg->motor_noise && cfg->substeps >= 2 && cfg->substeps <= 48) ? 1 : 0;
   if (const char* v = getenv("TE_DENSE_MIN")) { int n = atoi(v); if (n >= 1 && n <= 65) e->p.dense_min = n; }
   if (cfg->stacked_obs) e->n_fill_waves = 512;
   if (const char* v = getenv("TE_FILL_MODE")) e->fill_mode = atoi(v);
@@ -1290,10 +1353,17 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   launch_by_family(e->family, [&](auto fam) {
     constexpr int F = decltype(fam)::value;
     auto go = [&](auto noise_c, auto fill_c) {
-      if (p.cfg.control_every_substep)
-        TE_LAUNCH((substeps_kernel<F, decltype(noise_c)::value, decltype(fill_c)::value, true>), dim3(b1), dim3(TE_K1_BLOCK), 0, p, actions, fill);
+      constexpr bool kNoise = decltype(noise_c)::value;
+      if (kNoise && e->k1_help) {   // small shards: every flight (and candidate) block carries a second wave that prepares the motor noise
+        const size_t lds = (size_t)p.cfg.substeps * 1024 + 16;
+        if (p.cfg.control_every_substep)
+          TE_LAUNCH((substeps_kernel<F, kNoise, decltype(fill_c)::value, true, kNoise>), dim3(b1), dim3(128), lds, p, actions, fill);
+        else
+          TE_LAUNCH((substeps_kernel<F, kNoise, decltype(fill_c)::value, false, kNoise>), dim3(b1), dim3(128), lds, p, actions, fill);
+      } else if (p.cfg.control_every_substep)
+        TE_LAUNCH((substeps_kernel<F, kNoise, decltype(fill_c)::value, true>), dim3(b1), dim3(TE_K1_BLOCK), 0, p, actions, fill);
       else
-        TE_LAUNCH((substeps_kernel<F, decltype(noise_c)::value, decltype(fill_c)::value, false>), dim3(b1), dim3(TE_K1_BLOCK), 0, p, actions, fill);
+        TE_LAUNCH((substeps_kernel<F, kNoise, decltype(fill_c)::value, false>), dim3(b1), dim3(TE_K1_BLOCK), 0, p, actions, fill);
     };
     if (noise) { if (fill.lidar) go(std::true_type{}, std::true_type{}); else go(std::true_type{}, std::false_type{}); }
     else { if (fill.lidar) go(std::false_type{}, std::true_type{}); else go(std::false_type{}, std::false_type{}); }
