@@ -180,7 +180,7 @@ struct EnvIO {
 };
 
 // cfg.drone_contact: armed drones as spheres of contact_radius, resolved once per env.step on the state the sub-step launch left, pairs
-// in slot order, one pass (oracle: drone_contacts).  Compiled into the CONTACT instantiations of engage_kernel only: its 6 * DM
+// in slot order, one pass (SEMANTICS.md; oracle: drone_contacts).  Compiled into the CONTACT instantiations of engage_kernel only: its 6 * DM
 // registers would otherwise count against every launch (210 -> 363 VGPRs for <2, 9>) although the switch is off in every preset.
 template <int DM>
 TE_DEV void drone_contact_pass(const Params& p, int env, bool valid, uint64_t A) {

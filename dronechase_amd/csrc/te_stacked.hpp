@@ -2,7 +2,7 @@
 // (reference: core/entities/quadcopters/components/sensors/fused_lidar.py:73-109,143-262,293-326;
 //  components/lidar_buffer.py:10-157; components/lidar_math.py:186-345; threatsense/level5/level5_envrionment.py:312-351).
 //
-// Canonical clock: the ring entry of env-step s holds a wingman's IMU pose of step s and the kept
+// Canonical clock (SEMANTICS.md): the ring entry of env-step s holds a wingman's IMU pose of step s and the kept
 // features of its own sphere built from the poses of step s; at step t the entry of step t has age 1
 // (normalized_delta 0.1, as in the own sphere) and an entry of age a is the one of step t - a + 1.
 //

@@ -801,7 +801,7 @@ OTE_API void ote_own_sphere_from_poses(int D, int P, const double* pos, const do
 /* ------------------------------------------------------------------------- */
 /* level5: snapshot ring + FusedLIDAR stacked observation                                        */
 /* (fused_lidar.py:73-109,143-262,293-326; lidar_buffer.py:10-157; lidar_math.py:186-345)        */
-/* Canonical clock: the entry of env-step s holds the wingman's IMU pose of step s  */
+/* Canonical clock (SEMANTICS.md): the entry of env-step s holds the wingman's IMU pose of step s  */
 /* and the kept features of its own sphere built from the poses of step s; at step t the entry of */
 /* step t has age 1 (normalized_delta 0.1, as in the own sphere), an entry of age a is step t-a+1.*/
 /* ------------------------------------------------------------------------- */
