@@ -132,6 +132,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    # read by the ROCm runtime / RCCL when they initialise: set before torch touches the GPU
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool
+    os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")     # an RCCL collective that times out raises here (and the run falls back to gloo) instead of aborting the rank
     import torch
     import torch.distributed as dist
 
@@ -159,10 +162,9 @@ def main():
     local_dev = local_rank % n_dev
     torch.cuda.set_device(local_dev)
     device = torch.device("cuda", local_dev)
-    rccl, control_plane = None, "single process"
+    rccl, rccl_broken, control_plane = None, False, "single process"
     if world > 1:
         import datetime
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
         control_plane = "gloo (TE_BENCH_BACKEND=gloo)"
         if backend == "nccl" and world > n_dev:
@@ -182,7 +184,8 @@ def main():
             if int(agree.item()) == 1:
                 control_plane = "rccl (nccl backend: barrier + max-over-ranks; gloo default group underneath)"
             else:
-                rccl, control_plane = None, f"gloo (RCCL group did not come up on every rank{': ' + why if why else ''})"
+                rccl, rccl_broken = None, True
+                control_plane = f"gloo (RCCL group did not come up on every rank{': ' + why if why else ''})"
         dist.barrier()
 
     def barrier():
@@ -469,6 +472,9 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if rccl_broken:   # a communicator that failed to come up may not tear down either: the line is out, leave without the destructor
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
