@@ -286,6 +286,13 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   float ag[9];  // OBS_EULER, OBS_VEL, OBS_RATE of the agent
 #pragma unroll
   for (int k = 0; k < 9; ++k) ag[k] = __uint_as_float(ld(TE_D_OBS_EULER + k, 0));
+  // level5: the wingmen's attitudes go into the snapshot planes below.  Requested HERE, with everything else: read where they are stored
+  // (the planes may alias as far as the compiler knows) every one of the 3 * P words waited for the stores in front of it, 8 us of a 41 us launch
+  uint32_t se[3][PM];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int q = 0; q < PM; ++q) se[k][q] = (p.snap && q < P) ? ld(TE_D_OBS_EULER + k, q) : 0u;
   int step = (int)le(TE_E_STEP) + 1;  // AGENT_STEP_BROADCAST (exp03_vFinal_environment.py:177-182)
   int max_step = (int)le(TE_E_MAX_STEP);
   int round = (int)le(TE_E_ROUND);
@@ -393,9 +400,13 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   TE_ESTAMP(4, 0);
   // ---- the agent's own sphere: LidarMath.reframe + binning of every other drone armed NOW, closer wins in slot order
   // (fused_lidar.py:143-217, lidar_math.py:53-83,262-311); empty right after a reset (step 0 never gets here)
+  // (a stacked-observation env has no own-sphere output at all — ring_push_kernel / stack_view_kernel draw its spheres from the snapshot
+  // planes below — and skips the binning on a scalar test: 17 to 36 asin / atan2 pairs per lane that nothing reads)
   M owners = 0;
   uint32_t cell[DM]; float rhat[DM];
-  {
+#pragma unroll
+  for (int j = 0; j < DM; ++j) { cell[j] = 0u; rhat[j] = 1.0f; }
+  if (o.obs.lidar || o.term.lidar) {
     const M3 R = x_inverse_attitude(ag[0], ag[1], ag[2]);
 #pragma unroll
     for (int j = 1; j < DM; ++j) {   // every slot is binned, armed or not (branch-free, as above); only armed ones may own a cell
@@ -426,13 +437,17 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
         p.snap[(size_t)(sr.pos() + 2 * D + s) * p.Npad + env] = __float_as_uint(pz[s]);
       }
     }
+#pragma unroll
     for (int k = 0; k < 3; ++k)
-      for (int s = 0; s < P; ++s) p.snap[(size_t)(sr.euler() + k * P + s) * p.Npad + env] = (uint32_t)g.gi(TE_D_OBS_EULER + k, s);
+#pragma unroll
+      for (int s = 0; s < PM; ++s)
+        if (s < P) p.snap[(size_t)(sr.euler() + k * P + s) * p.Npad + env] = se[k][s];
     p.snap[(size_t)sr.armed() * p.Npad + env] = (uint32_t)A; p.snap[(size_t)sr.armed_hi() * p.Npad + env] = (uint32_t)((uint64_t)A >> 32);
     p.snap[(size_t)sr.step() * p.Npad + env] = (uint32_t)step;
     p.snap[(size_t)sr.episode() * p.Npad + env] = episode;
     p.snap[(size_t)sr.done() * p.Npad + env] = to_terminal ? 1u : 0u;
   }
+  TE_ESTAMP(12, 0);
   // ---- terminal observation of an auto-reset env (SB3 VecEnv: infos[i]["terminal_observation"]): rows from this lane
   auto inertial_row = [&](float* dst, float x, float y, float z, const float a9[9], int mu, int lfi, int st) {
     const float two_pi = 2.0f * kPi;
@@ -488,6 +503,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     }
   }
 
+  TE_ESTAMP(13, 0);
   // compute_reward (:423-515); Evaluation_Task.compute_reward returns 0 (evaluation_task.py:508-515)
   float reward = 0.0f, cur_dist = last_dist;
   if (!c.evaluation) {
@@ -549,6 +565,7 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
     reward = score + bonus - penalty;
     }
   }
+  TE_ESTAMP(14, 0);
   if (valid) {
     if (!c.evaluation) stef(TE_E_LAST_DIST, cur_dist);
     ste(TE_E_AGENT_KILLS, (uint32_t)agent_kills); ste(TE_E_ALLIES_KILLS, (uint32_t)allies_kills); ste(TE_E_DEADS, (uint32_t)deads);

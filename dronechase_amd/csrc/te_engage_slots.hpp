@@ -412,6 +412,407 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
   TE_WSTAMP(7, 1);
 }
 
+// ---- the level5 family (cfg.stacked_obs: te_step_stacked) in the same form.  No own sphere here — ring_push_kernel / stack_view_kernel draw
+// every sphere from the snapshot planes this kernel leaves (te_stacked.hpp SnapRows) — but more drones than a workgroup has waves: wave w
+// carries the slots w, w + W, ... (SPW of them, W = ceil(D / SPW) waves), so that the P wingmen are the FIRST slot of the first P waves
+// (P <= W, D <= 32: level5 6 + 12 with SPW = 2; level5_c1 2 + 10 with SPW = 1).  Bit for bit what engage_kernel<6, 12> leaves.  What the
+// lone wave of engage_kernel spends at 65 536 envs (tools/engage_stamps.py, level5): requests 6.5 us, closest invaders 3.5, shots 3.8,
+// snapshot planes + reward 7, rows 2.5, the five allies' behaviour trees 9, plan 1.3 — here every one of these is one slot's share.
+// LDS rows of engage_slots_stacked_kernel (256 B each): no cell rows, one record row per wingman — 30 KB for level5, four workgroups per CU
+struct StackedSlotRows {
+  int D, P;
+  TE_DEV int accS() const { return 0; }
+  TE_DEV int accZone() const { return 1; }
+  TE_DEV int accOrg() const { return 2; }
+  TE_DEV int pos(int k, int s) const { return 3 + k * D + s; }
+  TE_DEV int npos(int k, int s) const { return 3 + (3 + k) * D + s; }
+  TE_DEV int prec(int q) const { return 3 + 6 * D + q; }
+};
+__host__ __device__ inline int stacked_slot_lds_rows(int D, int P) { return 3 + 6 * D + P; }
+
+template <int SPW>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ? 4 : 6))) void engage_slots_stacked_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+  TE_EXACT
+  extern __shared__ uint32_t sm[];
+  const te_config& c = p.cfg;
+  const int D = p.D, P = c.n_pursuers;
+  const int W = (int)(blockDim.x >> 6);
+  const StackedSlotRows R{D, P};
+  const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave; its first slot
+  const int env = blockIdx.x * 64 + lane;
+  const bool valid = env < p.N;
+  const GView g{p.dstate, p.estate, D, p.Npad, env, P};
+  const EnvIO io(p, env);
+  const uint32_t pur_bits = (1u << P) - 1u, all_bits = D >= 32 ? ~0u : (1u << D) - 1u, inv_bits = all_bits & ~pur_bits;
+  const bool scripted = all_scripted(c);
+  const bool is_p = s < P;
+  int sl[SPW]; bool has[SPW];
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) { sl[u] = s + u * W; has[u] = sl[u] < D; }
+  auto L = [&](int row) -> uint32_t& { return sm[row * 64 + lane]; };
+  auto Lf = [&](int row) { return __uint_as_float(sm[row * 64 + lane]); };
+  auto Lor = [&](int row, uint32_t v) { __hip_atomic_fetch_or(&sm[row * 64 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  TE_WSTAMP(0, 0);
+
+  // ---- P0 (see engage_slots_kernel) -------------------------------------------------------------------------------------------------------
+  const uint32_t* __restrict__ lm32 = reinterpret_cast<const uint32_t*>(p.live_mask);
+  const uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane(lm32[2 * blockIdx.x]) & all_bits;   // D <= 32
+  auto next_round_of = [&](int r) { return r + (r < c.n_rounds ? 1 : c.n_rounds); };   // advance_round (exp03_vFinal_task.py:155-175)
+  auto may_be_spawned = [&](int slot, int r) { const int i = slot - P; return i < invaders_in_round(c, next_round_of(r)) || i < invaders_in_round(c, 1); };
+  bool mine_live[SPW]; bool any_live = is_p;
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) { mine_live[u] = has[u] && ((u == 0 && is_p) || ((live >> (sl[u] & 31)) & 1u)); any_live = any_live || mine_live[u]; }
+  if (!any_live) {   // none of this wave's slots is armed anywhere in the chunk, none can be armed by this step: the wave retires
+    const int r = (int)io.le(TE_E_ROUND);
+    bool maybe = false;
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) maybe = maybe || (has[u] && may_be_spawned(sl[u], r));
+    if (__ballot(valid && maybe) == 0ull) return;
+  }
+  float mx[SPW], my[SPW], mz[SPW]; uint32_t marmed_w[SPW];
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) {   // (a slot beyond D repeats the first one's rows: every request unconditional)
+    const int ls = has[u] ? sl[u] : s;
+    mx[u] = io.ldf(TE_D_OBS_POS, ls); my[u] = io.ldf(TE_D_OBS_POS + 1, ls); mz[u] = io.ldf(TE_D_OBS_POS + 2, ls);
+    marmed_w[u] = io.ld(TE_D_ARMED, ls);
+  }
+  const uint32_t w_step = io.le(TE_E_STEP), w_max_step = io.le(TE_E_MAX_STEP), w_round = io.le(TE_E_ROUND), w_episode = io.le(TE_E_EPISODE);
+  float ag[9];  // OBS_EULER, OBS_VEL, OBS_RATE of the agent: wave 0 (reward, rows)
+#pragma unroll
+  for (int k = 0; k < 9; ++k) ag[k] = 0.0f;
+  uint32_t w_last_dist = 0u, w_ak = 0u, w_lk = 0u, w_dd = 0u;
+  float4 act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (s == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ag[k] = io.ldf(TE_D_OBS_EULER + k, 0);
+    w_last_dist = io.le(TE_E_LAST_DIST); w_ak = io.le(TE_E_AGENT_KILLS); w_lk = io.le(TE_E_ALLIES_KILLS); w_dd = io.le(TE_E_DEADS);
+    if (valid) act = reinterpret_cast<const float4*>(actions)[env];
+  }
+  uint32_t w_mun = 0u, w_lf = 0u, eul[3] = {0u, 0u, 0u}; float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+  if (is_p) {   // gun, formation point, and the attitude the snapshot planes keep of a wingman
+    w_mun = io.ld(TE_D_MUNITION, s); w_lf = io.ld(TE_D_LAST_FIRED, s);
+    fx = io.ldf(TE_D_FORMATION, s); fy = io.ldf(TE_D_FORMATION + 1, s); fz = io.ldf(TE_D_FORMATION + 2, s);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) eul[k] = io.ld(TE_D_OBS_EULER + k, s);
+  }
+  uint32_t zero = 0u;
+  asm volatile("" : "+s"(zero));
+  if (s == 0) { L(R.accS()) = 0u; L(R.accZone()) = 0u; L(R.accOrg()) = 0u; }
+  TE_SLOT_BARRIER();   // barrier 0: the accumulator rows are zero
+  int step = (int)w_step + 1;  // AGENT_STEP_BROADCAST (exp03_vFinal_environment.py:177-182)
+  int max_step = (int)w_max_step, round = (int)w_round;
+  uint32_t episode = w_episode;
+  int mun = (int)w_mun, lf = (int)w_lf;
+  const float last_dist = __uint_as_float(w_last_dist);
+  int agent_kills = (int)w_ak, allies_kills = (int)w_lk, deads = (int)w_dd;
+  TE_WSTAMP(1, 1);
+
+  // ---- P1: own slots: flags and positions -------------------------------------------------------------------------------------------------
+  uint32_t a_me[SPW];
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) {
+    if (!mine_live[u]) { mx[u] = my[u] = mz[u] = 0.0f; }
+    a_me[u] = (mine_live[u] && marmed_w[u] != zero && valid) ? 1u : 0u;
+    if (has[u]) {
+      const float n = fnorm(V3{mx[u], my[u], mz[u]});
+      const int sh = sl[u] & 31;
+      Lor(R.accS(), a_me[u] << sh); Lor(R.accZone(), (a_me[u] & (n > c.dome_radius ? 1u : 0u)) << sh); Lor(R.accOrg(), (a_me[u] & (n < c.origin_range ? 1u : 0u)) << sh);
+      L(R.pos(0, sl[u])) = __float_as_uint(mx[u]); L(R.pos(1, sl[u])) = __float_as_uint(my[u]); L(R.pos(2, sl[u])) = __float_as_uint(mz[u]);
+    }
+  }
+  TE_WSTAMP(2, 0);
+  TE_SLOT_BARRIER();
+  TE_WSTAMP(3, 0);
+  const uint32_t S = L(R.accS()), zone = L(R.accZone()), org = L(R.accOrg());
+  const V3 apos{Lf(R.pos(0, 0)), Lf(R.pos(1, 0)), Lf(R.pos(2, 0))};
+  // ---- pursuer wave: identify_closest_invader (offsets_handler.py:256-281), process_shoot_range_invaders /
+  // process_explosion_range_invaders (exp03_vFinal_task.py:359-413) for ITS pursuer
+  if (is_p) {
+    int tgt = -1; float dmin = 0.0f;
+    for (uint32_t m = live & inv_bits; m; m &= m - 1u) {   // strict '<' in slot order, over the slots somebody of the chunk has armed
+      const int j = __ffs((int)m) - 1;
+      const float d = fdist(V3{mx[0], my[0], mz[0]}, V3{Lf(R.pos(0, j)), Lf(R.pos(1, j)), Lf(R.pos(2, j))});
+      const bool take = a_me[0] != 0u && ((S >> j) & 1u) != 0u && (tgt < 0 || d < dmin);
+      tgt = take ? j : tgt;
+      dmin = take ? d : dmin;
+    }
+    uint32_t rec = (uint32_t)(tgt + 1);
+    if (a_me[0] && tgt >= 0 && dmin < c.shoot_range && gun_available(c, mun, lf, step) && mun > 0) {
+      mun -= 1; lf = step;
+      io.st(TE_D_MUNITION, s, (uint32_t)mun); io.st(TE_D_LAST_FIRED, s, (uint32_t)step);
+      const U4 r = env_rng(c, env, RNG_HIT, (uint32_t)s, 0, episode, (uint32_t)step);
+      if (u01(r.x) < c.hit_prob) {  // gun.py:94; entities_manager.shoot_by_ids (:238-248)
+        rec |= SLOT_HIT;
+        if (c.evaluation) g.si(TE_D_KILLS, s, g.gi(TE_D_KILLS, s) + 1);  // lw_kills (evaluation_task.py:498-499)
+      }
+    }
+    if (a_me[0] && tgt >= 0 && dmin < c.explosion_range) rec |= SLOT_EXPLODE | (mun == 0 ? SLOT_SUICIDE : 0u);
+    L(R.prec(s)) = rec;
+  }
+  TE_SLOT_BARRIER();   // barrier 1b: the pursuers' records
+
+  // ---- P3: the engagement, by every wave ----------------------------------------------------------------------------------------------------
+  uint32_t killed = 0u;
+  int agent_shots = 0, ally_shots = 0, exploded = 0, pursuer_suicided = 0, agent_suicided = 0;
+  for (int q = 0; q < P; ++q) {
+    const uint32_t r = L(R.prec(q));
+    const int t = (int)(r & 0xFFu) - 1;
+    if (r & SLOT_HIT) { killed |= 1u << t; if (q == 0) agent_shots += 1; else ally_shots += 1; }
+    if (r & SLOT_EXPLODE) {
+      killed |= (1u << q) | (1u << t);
+      if ((r & SLOT_SUICIDE) && q == 0) agent_suicided += 1;
+      else if (r & SLOT_SUICIDE) pursuer_suicided += 1;
+      else exploded += 1;
+    }
+  }
+  // process_invaders_in_origin (:656-659); commented out in Evaluation_Task.on_step_middle (evaluation_task.py:397)
+  if ((!c.evaluation || (c.evaluation & TE_EVAL_ORIGIN_RULE)) && valid) killed |= org & inv_bits;
+  const uint32_t A = S & ~killed;
+#pragma unroll
+  for (int u = 0; u < SPW; ++u)
+    if (has[u] && ((killed >> (sl[u] & 31)) & 1u)) io.disarm(sl[u]);   // Quadcopter.disarm (quadcopter.py:461-478)
+  // increment_max_step (:150-153), compute_termination (:517-569)
+  if (agent_shots + ally_shots > 0) max_step += c.step_increment;
+  const int armed_invaders = __popc(A & inv_bits), armed_pursuers = __popc(A & pur_bits);
+  const bool all_rounds_over = armed_invaders == 0 && round >= c.n_rounds;
+  bool term;
+  if (c.evaluation) term = (c.max_step > 0 && step > max_step) || all_rounds_over || zone != 0u || armed_pursuers == 0;
+  else term = step > max_step || all_rounds_over || zone != 0u || armed_pursuers == 0 || (c.agent_death_terminates && !(A & 1u)) || apos.z < -5.99f;
+  const bool to_terminal = valid && term && c.auto_reset;
+  // ---- what this step's stacked observation may look at, BEFORE anything respawns (te_stacked.hpp SnapRows): every wave its slots' rows
+  if (p.snap && valid) {
+    const SnapRows sr{D, P};
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) {
+      if (has[u]) {
+        p.snap[(size_t)(sr.pos() + 0 * D + sl[u]) * p.Npad + env] = __float_as_uint(mx[u]);
+        p.snap[(size_t)(sr.pos() + 1 * D + sl[u]) * p.Npad + env] = __float_as_uint(my[u]);
+        p.snap[(size_t)(sr.pos() + 2 * D + sl[u]) * p.Npad + env] = __float_as_uint(mz[u]);
+      }
+    }
+    if (is_p) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p.snap[(size_t)(sr.euler() + k * P + s) * p.Npad + env] = eul[k];
+    }
+    if (s == 0) {
+      p.snap[(size_t)sr.armed() * p.Npad + env] = A; p.snap[(size_t)sr.armed_hi() * p.Npad + env] = 0u;
+      p.snap[(size_t)sr.step() * p.Npad + env] = (uint32_t)step;
+      p.snap[(size_t)sr.episode() * p.Npad + env] = episode;
+      p.snap[(size_t)sr.done() * p.Npad + env] = to_terminal ? 1u : 0u;
+    }
+  }
+
+  // ---- wave 0: reward, env record, outputs (exp03_vFinal_task.py:423-578 and the level5 reward models) -----------------------------------
+  auto pos_of = [&](int t) { return V3{__uint_as_float(sm[R.pos(0, t) * 64 + lane]), __uint_as_float(sm[R.pos(1, t) * 64 + lane]), __uint_as_float(sm[R.pos(2, t) * 64 + lane])}; };
+  if (s == 0) {
+    if (valid) {
+      io.stef(TE_E_LAST_ACTION + 0, act.x); io.stef(TE_E_LAST_ACTION + 1, act.y); io.stef(TE_E_LAST_ACTION + 2, act.z); io.stef(TE_E_LAST_ACTION + 3, act.w);
+      io.ste(TE_E_STEP, (uint32_t)step);
+      io.ste(TE_E_SNAP_MASK, S); io.ste(TE_E_SNAP_MASK_HI, 0u);
+    }
+    agent_kills += agent_shots; allies_kills += ally_shots; deads += exploded;
+    if (to_terminal) {
+      if (o.term.inertial) inertial_row_regs(c, o.term.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, mx[0], my[0], mz[0], ag, mun, lf, step);
+      if (o.term.last_action) reinterpret_cast<float4*>(o.term.last_action)[env] = act;
+    }
+    float reward = 0.0f, cur_dist = last_dist;
+    if (!c.evaluation) {
+      float gs[3];
+      gun_state(c, mun, lf, step, max_munition_of(c, 0), gs);
+      const float dist_origin = fnorm(apos);
+      int ally = -1;  // identify_closest_ally (offsets_handler.py:167-190)
+      if ((S & 1u) && __popc(S & pur_bits) > 1) {
+        float bd = 0.0f;
+        for (int a = 1; a < P; ++a) {
+          if ((S >> a) & 1u) {
+            const float d = fdist(pos_of(a), apos);
+            if (ally < 0 || d < bd) { ally = a; bd = d; }
+          }
+        }
+      }
+      const int chooser = ally < 0 ? 0 : ally;   // the reward's target: the closest invader of the agent's closest ally, or of the agent alone
+      const int target = ((S >> chooser) & 1u) ? (int)(sm[R.prec(chooser) * 64 + lane] & 0xFFu) - 1 : -1;
+      const V3 tp = target >= 0 ? pos_of(target) : V3{0.0f, 0.0f, 0.0f};
+      cur_dist = fdist(apos, tp);
+      const bool ready = gs[2] == 1.0f || gs[0] == 0.0f;
+      float bonus = 0.0f, penalty = 0.0f;
+      if (c.reward_model == TE_REWARD_L5_DUMB) {  // Level5DumbMultiObjectTask.compute_reward (level5_dumb_multiobject_task.py:452-553)
+        const float SAFE = 5.0f;
+        float score = -cur_dist;
+        if (!ready) {                               // keep away while reloading: distance counts for, closeness against
+          score = cur_dist;
+          if (cur_dist < SAFE) penalty += (SAFE - cur_dist) / SAFE * 500.0f;
+        }
+        if (gs[2] == 0.0f && gs[0] > 0.0f && (cur_dist - last_dist) > 0.01f) bonus += 100.0f;
+        if (agent_shots > 0) bonus += (float)agent_shots * 1000.0f;
+        if (ally_shots > 0 || pursuer_suicided > 0) bonus += 0.5f * (float)(ally_shots + pursuer_suicided) * 1000.0f;
+        if (agent_suicided > 0) penalty += 2.0f * (float)agent_suicided * 1000.0f;
+        if (exploded > 0) penalty += 1000.0f * (float)exploded;
+        if (apos.z < -5.0f) penalty += fminf(-5.0f - apos.z, 1.0f) * 1000.0f;
+        if (zone & pur_bits) penalty += 1000.0f;
+        if (dist_origin > c.born_radius - 2.0f) penalty += fminf(dist_origin - (c.born_radius - 2.0f), 1000.0f);
+        reward = clampf(score + bonus - penalty, -3000.0f, 3000.0f);
+      } else if (c.reward_model == TE_REWARD_L5_C1) {  // Level5C1FusionTask.compute_reward (level5_c1_fusion_task.py:448-485)
+        const int t1 = (S & 1u) ? (int)(sm[R.prec(0) * 64 + lane] & 0xFFu) - 1 : -1;   // the agent's OWN closest invader (:458)
+        const float d1 = t1 >= 0 ? fdist(apos, pos_of(t1)) : dist_origin;
+        const float first = last_dist == 0.0f ? d1 : last_dist;   // `last_distance` is set by the first reward of the env and never again (:467-468)
+        float r1 = d1 < first ? c.approach_bonus_gain * fnorm(V3{ag[3], ag[4], ag[5]}) : 0.0f;
+        if (agent_shots > 0) r1 += (float)agent_shots * 1000.0f;
+        if (agent_suicided > 0) r1 -= 2.0f * (float)agent_suicided * 1000.0f;
+        reward = clampf(r1, -3000.0f, 3000.0f);
+        cur_dist = first;
+      } else {
+        if (0.01f < last_dist - cur_dist && ready) bonus += c.approach_bonus_gain * fnorm(V3{ag[3], ag[4], ag[5]});
+        const float score = ready ? -cur_dist : cur_dist * (2.0f * gs[1] - 1.0f);
+        if (agent_shots > 0 || agent_suicided > 0) bonus += (float)(agent_shots + agent_suicided) * 1000.0f;
+        if (ally_shots > 0 || pursuer_suicided > 0) bonus += 0.5f * (float)(ally_shots + pursuer_suicided) * 1000.0f;
+        else if (exploded > 0) penalty += 1000.0f * (float)exploded;
+        if (apos.z < -5.0f) penalty += (-5.0f - apos.z) * 1000.0f;
+        if (zone & pur_bits) penalty += 1000.0f;
+        if (dist_origin > c.born_radius - 2.0f) penalty += dist_origin - c.born_radius - 2.0f;  // literal
+        reward = score + bonus - penalty;
+      }
+    }
+    if (valid) {
+      if (!c.evaluation) io.stef(TE_E_LAST_DIST, cur_dist);
+      io.ste(TE_E_AGENT_KILLS, (uint32_t)agent_kills); io.ste(TE_E_ALLIES_KILLS, (uint32_t)allies_kills); io.ste(TE_E_DEADS, (uint32_t)deads);
+      if (agent_shots + ally_shots > 0) io.ste(TE_E_MAX_STEP, (uint32_t)max_step);
+      o.reward[env] = reward;
+      o.done[env] = term ? 1 : 0;
+      reinterpret_cast<int4*>(o.info)[env] = make_int4(agent_kills, allies_kills, deads, round);
+      io.ste(TE_E_INFO_WAVE, (uint32_t)round);   // (on_step_end below may start the next wave; an auto-reset puts 1 back)
+    }
+  }
+
+  // ---- on_step_end (:321-333): next wave when this one is cleared and a pursuer is alive; SB3 auto-reset (every wave decides, wave 0 stores)
+  uint32_t task = 0u;   // round | reset << 8: the slots of this env have to be respawned
+  uint32_t snap_mask = S;
+  auto mask_after_spawn = [&](int rnd, bool reset) {
+    const uint32_t m = reset ? pur_bits : (A & pur_bits);
+    const int n = invaders_in_round(c, rnd);
+    return (uint32_t)(m | ((uint32_t)((((uint64_t)1 << n) - 1u) << P) & all_bits));
+  };
+  if (valid && !term && armed_invaders == 0 && armed_pursuers > 0) {
+    round = round + (round < c.n_rounds ? 1 : c.n_rounds);  // advance_round (:155-175)
+    snap_mask = mask_after_spawn(round, false);
+    if (s == 0) { io.ste(TE_E_ROUND, (uint32_t)round); io.ste(TE_E_SNAP_MASK, snap_mask); io.ste(TE_E_SNAP_MASK_HI, 0u); }
+    task = (uint32_t)round;
+  }
+  if (to_terminal) {  // Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146): the env record by wave 0, every slot by its wave
+    episode += 1u; step = 0; max_step = c.max_step; round = 1;
+    snap_mask = mask_after_spawn(1, true);
+    if (s == 0) {
+      io.ste(TE_E_EPISODE, episode); io.ste(TE_E_STEP, 0u); io.ste(TE_E_MAX_STEP, (uint32_t)c.max_step); io.ste(TE_E_ROUND, 1u); io.ste(TE_E_INFO_WAVE, 1u);
+      io.ste(TE_E_AGENT_KILLS, 0u); io.ste(TE_E_ALLIES_KILLS, 0u); io.ste(TE_E_DEADS, 0u);
+      if (c.reward_model != TE_REWARD_L5_C1) io.stef(TE_E_LAST_DIST, c.dome_radius);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) io.ste(TE_E_LAST_ACTION + k, 0u);
+      io.ste(TE_E_SNAP_MASK, snap_mask); io.ste(TE_E_SNAP_MASK_HI, 0u);
+    }
+    act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ag[k] = 0.0f;
+    task = 1u | (1u << 8);
+  }
+  // ---- spawn of this wave's slots: every lane whose env starts a round or resets draws its own positions (Task.setup_round / on_reset)
+  if (task != 0u) {
+    const bool reset = (task >> 8) != 0u;
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) {
+      if (has[u]) {
+        V3 w{0.0f, 0.0f, 0.0f};
+        const bool placed = spawn_slot_at(c, g, sl[u], (int)(task & 0xFFu), episode, reset, ((A >> (sl[u] & 31)) & 1u) != 0u, w);
+        if (placed) { mx[u] = w.x; my[u] = w.y; mz[u] = w.z; }
+      }
+    }
+    if (reset && is_p) { mun = max_munition_of(c, s); lf = -c.cooldown_steps; fx = mx[0]; fy = my[0]; fz = mz[0]; }
+  }
+  if (s == 0 && __ballot(task != 0u) != 0ull) {   // the retired waves' share of Task.setup_round / on_reset: their invaders go back to WaitState
+    for (uint32_t m = inv_bits & ~live; m; m &= m - 1u) {
+      const int k2 = __ffs((int)m) - 1;
+      const int wv = k2 % W;
+      bool stayed = wv < P;   // did the wave that carries slot k2 stay?  (then it does this itself: spawn_slot_at)
+      for (int u2 = 0; u2 < SPW && !stayed; ++u2) {
+        const int s2 = wv + u2 * W;
+        if (s2 < D) stayed = ((live >> s2) & 1u) != 0u || __ballot(valid && may_be_spawned(s2, (int)w_round)) != 0ull;
+      }
+      if (stayed) continue;
+      if (task != 0u) io.st(TE_D_NAV_STATE, k2, (uint32_t)TE_NAV_WAIT);
+    }
+  }
+  const uint32_t armed_post = task != 0u ? snap_mask : A;   // after the spawn: the pursuers as they are (all armed on reset) + the round's invaders
+#pragma unroll
+  for (int u = 0; u < SPW; ++u)
+    if (has[u]) { L(R.npos(0, sl[u])) = __float_as_uint(mx[u]); L(R.npos(1, sl[u])) = __float_as_uint(my[u]); L(R.npos(2, sl[u])) = __float_as_uint(mz[u]); }
+  TE_WSTAMP(4, 0);
+  TE_SLOT_BARRIER();
+  TE_WSTAMP(5, 0);
+
+  // ---- P4 --------------------------------------------------------------------------------------------------------------------------------
+  if (s == 0) {   // the observation of the state the step leaves (post-reset values for an auto-reset env)
+    if (o.obs.inertial && valid) inertial_row_regs(c, o.obs.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, mx[0], my[0], mz[0], ag, mun, lf, step);
+    if (valid && o.obs.last_action) reinterpret_cast<float4*>(o.obs.last_action)[env] = act;
+  }
+  // ---- pursuer waves: TE_X_REF and the scripted wingman's command of the next step (loyalwingman_navigator.py:238-352)
+  if (is_p && valid) {
+    int first_skipped = -1;  // drive_loyalwingmen: get_armed_pursuers()[1:] — with the agent dead the first armed ally is skipped
+    if (!scripted && !(armed_post & 1u)) first_skipped = (armed_post & pur_bits & ~1u) ? __ffs((int)(armed_post & pur_bits & ~1u)) - 1 : -1;
+    io.stf(TE_X_REF + 0, s, mx[0]); io.stf(TE_X_REF + 1, s, my[0]); io.stf(TE_X_REF + 2, s, mz[0]);
+    if ((s > 0 || scripted) && ((armed_post >> s) & 1u) && s != first_skipped) {
+      float out[3] = {0.0f, 0.0f, 0.0f};
+      const bool ext = driven_externally(c, s);
+      if (!ext && c.ally_policy == TE_ALLY_BT) {
+        const V3 me{mx[0], my[0], mz[0]};
+        if (gun_available(c, mun, lf, step)) {
+          int t = -1; float bd = 0.0f; V3 tp{0.0f, 0.0f, 0.0f};
+          if ((snap_mask >> s) & 1u) {
+            for (int j = P; j < D; ++j) {
+              if (__ballot((snap_mask >> j) & 1u) == 0ull) continue;   // nobody of the chunk has slot j armed: its row is not read
+              if ((snap_mask >> j) & 1u) {
+                const V3 pj{Lf(R.npos(0, j)), Lf(R.npos(1, j)), Lf(R.npos(2, j))};
+                const float d = fdist(me, pj);
+                if (t < 0 || d < bd) { t = j; bd = d; tp = pj; }
+              }
+            }
+          }
+          x_cmd_toward(me, tp, c.ally_speed, out);
+        } else x_cmd_toward(me, V3{fx, fy, fz}, c.ally_speed, out);
+      } else if (ext || c.ally_policy != TE_ALLY_FROZEN) {  // nobody / the caller's policy: the set-point persists
+        out[0] = g.gf(TE_D_SETPOINT + 0, s); out[1] = g.gf(TE_D_SETPOINT + 1, s); out[2] = g.gf(TE_D_SETPOINT + 3, s);
+      }
+      io.stf(TE_X_CMD + 0, s, out[0]); io.stf(TE_X_CMD + 1, s, out[1]); io.stf(TE_X_CMD + 2, s, out[2]);
+    }
+  }
+  // ---- the next sub-step launch's flight plan: a wave walks the slots up to its highest one and writes its own items; the last pursuer
+  // wave walks them all and writes the chunk's masks
+  {
+    const int writer = P - 1;
+    int top = s;
+#pragma unroll
+    for (int u = 1; u < SPW; ++u) if (has[u]) top = sl[u];
+    uint64_t dense = 0u, livem = 0u; int n = 0;
+    uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
+    const int k_last = s == writer ? D - 1 : top;
+    for (int k = 0; k <= k_last; ++k) {
+      const bool a = valid && ((armed_post >> k) & 1u) != 0u;
+      const unsigned long long b = __ballot(a);
+      const int cnt = __popcll(b);
+      if (cnt == 0) continue;
+      livem |= (uint64_t)1 << k;
+      if (k == 0 || cnt >= p.dense_min || n + cnt > kMixedCap) { dense |= (uint64_t)1 << k; continue; }
+      bool own = false;
+#pragma unroll
+      for (int u = 0; u < SPW; ++u) own = own || (has[u] && k == sl[u]);
+      if (own && a) items[n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | (k << 8));
+      n += cnt;
+    }
+    if (s == writer && lane == 0) { p.slot_mask[blockIdx.x] = dense; p.mixed_count[blockIdx.x] = (uint32_t)n; p.live_mask[blockIdx.x] = livem; }
+  }
+  TE_WSTAMP(6, 0);
+  TE_WSTAMP(7, 1);
+}
+
 // ---- stage02 (L3Stage1.on_step_middle / on_step_end, level3/components/stages.py:144-179,241-344) in the same form: bit for bit what
 // engage_stage02_kernel<2, 8> writes.  Differences from the level4 family: the suicide rule (a pursuer without munition kills by contact at
 // shoot range), every kill counts for the agent, killed invaders come back inside the step, no waves, no behaviour tree.

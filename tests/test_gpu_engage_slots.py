@@ -122,3 +122,54 @@ def test_slot_waves_on_the_all_armed_state(monkeypatch):
         kills += int(oa[5][:, 0].sum().item())
     assert torch.equal(a.get_state(), b.get_state()) and kills > 1000
     a.close(); b.close()
+
+
+def _same_stacked_rollout(a, b, steps, seed=13, persistent=False):
+    import torch
+    if persistent:
+        a.set_persistent_obs(True); b.set_persistent_obs(True)
+    a.reset(); b.reset()
+    n_done = 0
+    for s in range(steps):
+        act = a.random_actions(seed, s)
+        oa, ob = a.step_stacked(act), b.step_stacked(act)
+        for k, (x, y) in enumerate(zip(oa, ob)):
+            assert torch.equal(x, y), f"output {k} differs at step {s}"
+        d = oa[5].bool()
+        n_done += int(d.sum().item())
+        if d.any():
+            for name in ("t_stacked", "t_mask", "t_inertial", "t_last_action"):
+                assert torch.equal(getattr(a, name)[d], getattr(b, name)[d]), f"{name} differs at step {s}"
+        if s % 8 == 7 or s == steps - 1:
+            assert torch.equal(a.get_state(), b.get_state()), f"state differs after step {s}"
+    return n_done
+
+
+@pytest.mark.parametrize("task,n,over", [
+    ("level5", 4096, {}), ("level5", 1000, {"seed": 3, "max_step": 25}), ("level5", 63, {"max_step": 12}),
+    ("level5_c1", 4096, {}), ("level5_c1", 1000, {"seed": 9, "max_step": 25}),
+    # odd slot counts: the last wave carries one slot only; more wingmen than half the waves
+    ("level5", 2048, {"n_invaders": 11, "n_rounds": 11, "max_step": 40}), ("level5", 2048, {"n_pursuers": 7, "n_invaders": 10, "n_rounds": 10, "max_step": 40}),
+])
+def test_stacked_slot_waves_equal_the_one_wave_kernel(monkeypatch, task, n, over):
+    """engage_slots_stacked_kernel<1 / 2> (the level5 family: wave w carries the slots w, w + W, ...) against engage_kernel<6, 12>: every output of
+    te_step_stacked, the terminal buffers and the state blob (snapshot ring included) along rollouts with shots, wave advances and auto-resets."""
+    a, b = _pair(monkeypatch, task, n, **over)
+    n_done = _same_stacked_rollout(a, b, 120)
+    assert n_done > 0 or "max_step" not in over
+    a.close(); b.close()
+    a, b = _pair(monkeypatch, task, n, **over)
+    _same_stacked_rollout(a, b, 40, persistent=True)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("task,spw,over", [("level5", 3, {"max_step": 30}), ("level5_c1", 2, {"max_step": 30}), ("level5_c1", 3, {}),
+                                            ("level5", 3, {"n_pursuers": 7, "n_invaders": 13, "n_rounds": 13, "max_step": 40})])
+def test_stacked_slot_waves_with_more_slots_per_wave(monkeypatch, task, spw, over):
+    """Large shards give a wave more slots (fewer waves per workgroup, every chunk resident at once): TE_SLOT_SPW forces that form on a small one."""
+    monkeypatch.setenv("TE_SLOT_SPW", str(spw))
+    a, b = _pair(monkeypatch, task, 3000, **over)
+    monkeypatch.delenv("TE_SLOT_SPW")
+    n_done = _same_stacked_rollout(a, b, 100)
+    assert n_done > 0 or "max_step" not in over
+    a.close(); b.close()

@@ -19,12 +19,14 @@ a = torch.empty((N, 4), device="cuda")
 nchunks = (N + 63) // 64
 base = 64 + 16 * (nchunks + 1)
 D = cfg.n_drones
-n_k1 = 256 + (D + 2) * nchunks
+n_fill = int(os.environ.get("TE_FILL_WAVES", 512 if cfg.stacked_obs else 256))
+n_k1 = n_fill + (D + 2) * nchunks
 words = base + 4 * n_k1
 buf = (C.c_uint64 * words)()
 for i in range(steps):
     env.random_actions(1234, i, out=a)
-    env.step(a, terminal=True)
+    if cfg.stacked_obs: env.step_stacked(a)
+    else: env.step(a, terminal=True)
     if i in (20, steps // 4, steps - 1):
         torch.cuda.synchronize()
         rc = env.L.te_debug_stamps(env._h, buf, words)
