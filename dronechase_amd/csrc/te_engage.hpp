@@ -409,14 +409,16 @@ __global__ __launch_bounds__(64) void engage_kernel(Params p, const float* __res
   if (o.obs.lidar || o.term.lidar) {
     const M3 R = x_inverse_attitude(ag[0], ag[1], ag[2]);
 #pragma unroll
-    for (int j = 1; j < DM; ++j) {   // every slot is binned, armed or not (branch-free, as above); only armed ones may own a cell
+    for (int j = 1; j < DM; ++j) {   // a slot somebody of the chunk has armed is binned in every lane (branch-free, as above); only armed ones may own a cell
+      if (!(j < D && ((live >> j) & 1u))) continue;   // wave-uniform: nobody has it armed, nobody looks at its cell (owners stays clear)
       int cj; lidar_cell_fast(c, x_mul(R, sub(V3{px[j], py[j], pz[j]}, apos)), cj, rhat[j]);
       cell[j] = (uint32_t)cj;
       const bool in = ((A >> j) & one) != 0;
       M same = 0;           // the current owner of the same cell, if any (at most one)
       float r_owner = 2.0f;
 #pragma unroll
-      for (int k = 1; k < j; ++k) {
+      for (int k = 1; k < j; ++k) {   // (a pair costs four VALU instructions; a compare + scalar branch per pair, with the bookkeeping only for
+                                      // pairs that do collide in some lane, was SLOWER here: + 3 us at DM = 11 and 32, a lone wave pays for every branch)
         const bool hit = ((owners >> k) & one) != 0 && cell[k] == cell[j];
         same |= (hit ? one : (M)0) << k;
         r_owner = hit ? rhat[k] : r_owner;

@@ -12,6 +12,7 @@
 // Same arithmetic, same helpers (spherical_of, rotate_by, draw_stack, ring layout) and the same order of every farther- / closer-wins
 // decision as stacked_kernel, which stays as the fallback for shapes beyond DM = 37 and behind TE_STACKED=lds.
 #pragma once
+#include <type_traits>
 #include <utility>
 
 #include "te_stacked.hpp"
@@ -64,22 +65,47 @@ __global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
     }
   });
   // ---- closer wins per cell (lidar_math.py:262-311), as in stacked_kernel: j CLAIMS its cell if it is in view with r_hat < 1; the kept
-  // feature of a cell is its closest claimant (ties: lowest slot); cells appear in the entry in the order of their first claimant
+  // feature of a cell is its closest claimant (ties: lowest slot); cells appear in the entry in the order of their first claimant.
+  // Two drones in one of the sphere's 338 cells are rare (a pair collides in 4 % of the waves), and every pair was paying for the full
+  // bookkeeping (7 VALU instructions x DM^2 pairs: 2 600 of the wave's 5 700 at DM = 18).  Now a pair costs ONE compare and a scalar branch:
+  // a drone that claims nothing gets a code no other slot has, so "same cell" is equality of the codes, and only a pair that does collide in
+  // some lane enters its bookkeeping: the later one is not the cell's first claimant (`later`), the farther one (ties: the higher slot) is
+  // `beaten`.  A cell's kept feature is its one unbeaten claimant: the first claimant itself, or — found by a search only a wave with
+  // such a lane runs — another one.
   uint32_t* ent = ring_entry_ptr(p.ring, p.entry_words, P, (size_t)env, pp, step);
+  using M = typename std::conditional<(DM > 32), uint64_t, uint32_t>::type;   // one bit per slot
+  constexpr M one = 1;
+  M later = 0, beaten = 0;
+  static_for<DM>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    cell[j] = (cell[j] != 0xFFFFFFFFu && rh[j] < 1.0f) ? cell[j] : (0xFFFF0000u | (uint32_t)j);   // from here on: the code
+  });
+  static_for<DM>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    if (j >= hi) return;   // wave-uniform
+    static_for<j>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      const bool same = cell[k] == cell[j];
+      if (__ballot(same) != 0ull) {
+        const bool k_closer = rh[k] <= rh[j];   // ties: the lower slot k stays
+        later |= same ? (one << j) : (M)0;
+        beaten |= same ? (k_closer ? (one << j) : (one << k)) : (M)0;
+      }
+    });
+  });
   uint32_t n = 0u;
   static_for<DM>([&](auto J) {
     constexpr int j = decltype(J)::value;
     if (j >= hi) return;   // wave-uniform
-    const bool claim = cell[j] != 0xFFFFFFFFu && rh[j] < 1.0f;
-    bool lead = claim;
+    const bool lead = cell[j] < 0xFFFF0000u && !((later >> j) & one);
     float br = rh[j], bt = th[j], bp = ph[j]; int bw = j;
-    static_for<DM>([&](auto K) {
-      constexpr int k = decltype(K)::value;
-      if (k == j || k >= hi) return;
-      const bool same = claim && cell[k] == cell[j] && rh[k] < 1.0f;   // cell[k] == 0xFFFFFFFF never equals a claimed cell
-      if (same && k < j) lead = false;
-      if (same && (rh[k] < br || (rh[k] == br && k < bw))) { br = rh[k]; bt = th[k]; bp = ph[k]; bw = k; }
-    });
+    if (__ballot(lead && ((beaten >> j) & one)) != 0ull) {   // the first claimant is not the closest one: the cell's unbeaten claimant
+      static_for<DM>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if (k <= j) return;   // (an earlier claimant of the cell would have made j a later one)
+        if (lead && ((beaten >> j) & one) && cell[k] == cell[j] && !((beaten >> k) & one)) { br = rh[k]; bt = th[k]; bp = ph[k]; bw = k; }
+      });
+    }
     if (lead) {
       const uint32_t meta = (uint32_t)(bw < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) | ((uint32_t)bw << 8);
       *reinterpret_cast<uint4*>(ent + TE_RING_HEADER_WORDS + 4 * n) = make_uint4(__float_as_uint(br), __float_as_uint(bt), __float_as_uint(bp), meta);
