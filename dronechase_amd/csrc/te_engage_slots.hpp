@@ -412,14 +412,19 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
   TE_WSTAMP(7, 1);
 }
 
-// ---- the level5 family (cfg.stacked_obs: te_step_stacked) in the same form.  No own sphere here — ring_push_kernel / stack_view_kernel draw
-// every sphere from the snapshot planes this kernel leaves (te_stacked.hpp SnapRows) — but more drones than a workgroup has waves: wave w
-// carries the slots w, w + W, ... (SPW of them, W = ceil(D / SPW) waves), so that the P wingmen are the FIRST slot of the first P waves
-// (P <= W, D <= 32: level5 6 + 12 with SPW = 2; level5_c1 2 + 10 with SPW = 1).  Bit for bit what engage_kernel<6, 12> leaves.  What the
+// ---- several slots per wave: wave w carries the slots w, w + W, ... (SPW of them, W = ceil(D / SPW) waves), so that the P wingmen are the
+// FIRST slot of the first P waves (P <= W, D <= 32).  Two uses:
+//   LIDAR = false  the level5 family (cfg.stacked_obs: te_step_stacked): more drones than a workgroup has waves (level5: 6 + 12), and no own
+//                  sphere — ring_push_kernel / stack_view_kernel draw every sphere from the snapshot planes this kernel leaves (SnapRows);
+//   LIDAR = true   the level4 family with the own sphere, where engage_slots_kernel's one slot per wave does not fit: level5_2bt's 2 + 30
+//                  drones (engage 53.5 -> 39.7 us at 65 536 envs).  On shapes both serve engage_slots_kernel stays ahead at every shard size
+//                  (most of its waves retire at once; profiles/r04_q_ab_slots_per_wave.txt); TE_SLOT_SPW=2 forces this one (tests).
+// Bit for bit what engage_kernel<PM, IM> leaves (and engage_slots_kernel, where both serve).  What the
 // lone wave of engage_kernel spends at 65 536 envs (tools/engage_stamps.py, level5): requests 6.5 us, closest invaders 3.5, shots 3.8,
 // snapshot planes + reward 7, rows 2.5, the five allies' behaviour trees 9, plan 1.3 — here every one of these is one slot's share.
-// LDS rows of engage_slots_stacked_kernel (256 B each): no cell rows, one record row per wingman — 30 KB for level5, four workgroups per CU
-struct StackedSlotRows {
+// LDS rows of engage_slots_multi_kernel (256 B each): one record row per wingman; the {cell, range} pairs and the owner row behind the rest
+// (LIDAR only) — 30 KB for level5, four workgroups per CU
+struct MultiSlotRows {
   int D, P;
   TE_DEV int accS() const { return 0; }
   TE_DEV int accZone() const { return 1; }
@@ -427,17 +432,19 @@ struct StackedSlotRows {
   TE_DEV int pos(int k, int s) const { return 3 + k * D + s; }
   TE_DEV int npos(int k, int s) const { return 3 + (3 + k) * D + s; }
   TE_DEV int prec(int q) const { return 3 + 6 * D + q; }
+  TE_DEV int accOwn() const { return 3 + 6 * D + P; }
+  TE_DEV int cellr(int s) const { return 4 + 6 * D + P + 2 * s; }   // 8-byte {cell, range} per lane: two rows
 };
-__host__ __device__ inline int stacked_slot_lds_rows(int D, int P) { return 3 + 6 * D + P; }
+__host__ __device__ inline int multi_slot_lds_rows(int D, int P, bool lidar) { return 3 + 6 * D + P + (lidar ? 1 + 2 * D : 0); }
 
-template <int SPW>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ? 4 : 6))) void engage_slots_stacked_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+template <int SPW, bool LIDAR>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ? 4 : 6))) void engage_slots_multi_kernel(Params p, const float* __restrict__ actions, StepOut o) {
   TE_EXACT
   extern __shared__ uint32_t sm[];
   const te_config& c = p.cfg;
   const int D = p.D, P = c.n_pursuers;
   const int W = (int)(blockDim.x >> 6);
-  const StackedSlotRows R{D, P};
+  const MultiSlotRows R{D, P};
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave; its first slot
   const int env = blockIdx.x * 64 + lane;
@@ -478,14 +485,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
     marmed_w[u] = io.ld(TE_D_ARMED, ls);
   }
   const uint32_t w_step = io.le(TE_E_STEP), w_max_step = io.le(TE_E_MAX_STEP), w_round = io.le(TE_E_ROUND), w_episode = io.le(TE_E_EPISODE);
-  float ag[9];  // OBS_EULER, OBS_VEL, OBS_RATE of the agent: wave 0 (reward, rows)
+  float ag[9];  // OBS_EULER, OBS_VEL, OBS_RATE of the agent: wave 0 (reward, rows); with the own sphere every wave needs the attitude and the position
 #pragma unroll
   for (int k = 0; k < 9; ++k) ag[k] = 0.0f;
+  V3 apos0{0.0f, 0.0f, 0.0f};
+  if (LIDAR) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ag[k] = io.ldf(TE_D_OBS_EULER + k, 0);
+    apos0 = V3{io.ldf(TE_D_OBS_POS, 0), io.ldf(TE_D_OBS_POS + 1, 0), io.ldf(TE_D_OBS_POS + 2, 0)};
+  }
   uint32_t w_last_dist = 0u, w_ak = 0u, w_lk = 0u, w_dd = 0u;
   float4 act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (s == 0) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) ag[k] = io.ldf(TE_D_OBS_EULER + k, 0);
+    for (int k = LIDAR ? 3 : 0; k < 9; ++k) ag[k] = io.ldf(TE_D_OBS_EULER + k, 0);
     w_last_dist = io.le(TE_E_LAST_DIST); w_ak = io.le(TE_E_AGENT_KILLS); w_lk = io.le(TE_E_ALLIES_KILLS); w_dd = io.le(TE_E_DEADS);
     if (valid) act = reinterpret_cast<const float4*>(actions)[env];
   }
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
   }
   uint32_t zero = 0u;
   asm volatile("" : "+s"(zero));
-  if (s == 0) { L(R.accS()) = 0u; L(R.accZone()) = 0u; L(R.accOrg()) = 0u; }
+  if (s == 0) { L(R.accS()) = 0u; L(R.accZone()) = 0u; L(R.accOrg()) = 0u; if (LIDAR) L(R.accOwn()) = 0u; }
   TE_SLOT_BARRIER();   // barrier 0: the accumulator rows are zero
   int step = (int)w_step + 1;  // AGENT_STEP_BROADCAST (exp03_vFinal_environment.py:177-182)
   int max_step = (int)w_max_step, round = (int)w_round;
@@ -519,6 +532,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
       const int sh = sl[u] & 31;
       Lor(R.accS(), a_me[u] << sh); Lor(R.accZone(), (a_me[u] & (n > c.dome_radius ? 1u : 0u)) << sh); Lor(R.accOrg(), (a_me[u] & (n < c.origin_range ? 1u : 0u)) << sh);
       L(R.pos(0, sl[u])) = __float_as_uint(mx[u]); L(R.pos(1, sl[u])) = __float_as_uint(my[u]); L(R.pos(2, sl[u])) = __float_as_uint(mz[u]);
+    }
+  }
+  // own slots' LIDAR cells in the agent's frame (fused_lidar.py:143-217, lidar_math.py:53-83,262-311)
+  int cj[SPW]; float rh[SPW];
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) { cj[u] = 0; rh[u] = 1.0f; }
+  if (LIDAR) {
+    const M3 Rm = x_inverse_attitude(ag[0], ag[1], ag[2]);
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) {
+      if (has[u] && sl[u] >= 1) {
+        lidar_cell_fast(c, x_mul(Rm, sub(V3{mx[u], my[u], mz[u]}, apos0)), cj[u], rh[u]);
+        *reinterpret_cast<uint2*>(&sm[R.cellr(sl[u]) * 64 + 2 * lane]) = make_uint2((uint32_t)cj[u], __float_as_uint(rh[u]));
+      }
     }
   }
   TE_WSTAMP(2, 0);
@@ -580,6 +607,47 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
   if (c.evaluation) term = (c.max_step > 0 && step > max_step) || all_rounds_over || zone != 0u || armed_pursuers == 0;
   else term = step > max_step || all_rounds_over || zone != 0u || armed_pursuers == 0 || (c.agent_death_terminates && !(A & 1u)) || apos.z < -5.99f;
   const bool to_terminal = valid && term && c.auto_reset;
+  // ---- closer wins (lidar_math.py:262-311) as a fixed point: in every cell the armed drone of smallest (range, slot); a drone at range 1.0
+  // never owns a cell.  Only slots some env of the chunk has armed can contest a cell.  Patches: flag = type / 5 (lidar_math.py:305), the
+  // time plane is Delta 1 of a 10-deep ring (perception_snapshot.py:36-37)
+  bool own[SPW];
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) own[u] = false;
+  const bool time_plane = c.lidar_channels != 2;
+  auto patch = [&](float* dst, int cell, float range, int slot) {
+    dst += (size_t)env * lidar_words(c);
+    dst[cell] = range; dst[TE_LIDAR_CELLS + cell] = (float)(slot < P ? TE_TYPE_LOYALWINGMAN : TE_TYPE_LOITERINGMUNITION) / 5.0f;
+    if (time_plane) dst[2 * TE_LIDAR_CELLS + cell] = 0.1f;
+  };
+  unsigned long long term_b = 0ull;
+  if (LIDAR) {
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) {
+      if (has[u] && sl[u] >= 1) {
+        const int me = sl[u];
+        bool mine = ((A >> (me & 31)) & 1u) != 0u && rh[u] < 1.0f;
+        for (uint32_t m = live & ~1u & ~(1u << (me & 31)); m; m &= m - 1u) {
+          const int k2 = __ffs((int)m) - 1;
+          const uint2 cr = *reinterpret_cast<const uint2*>(&sm[R.cellr(k2) * 64 + 2 * lane]);
+          const float rk = __uint_as_float(cr.y);
+          const bool beaten = ((A >> k2) & 1u) != 0u && cr.x == (uint32_t)cj[u] && (rk < rh[u] || (rk == rh[u] && k2 < me));
+          mine = mine && !beaten;
+        }
+        own[u] = mine;
+        if (mine && valid) Lor(R.accOwn(), 1u << (me & 31));
+        if (valid && mine && !to_terminal && o.obs.lidar) patch(o.obs.lidar, cj[u], rh[u], me);
+      }
+    }
+    // terminal tiles: ones, the pursuer waves their shares (an invader wave may have retired); acknowledged before barrier 2, behind which the owners patch them
+    term_b = __ballot(to_terminal);
+    if (o.term.lidar && term_b && is_p) {
+      for (unsigned long long tb = term_b; tb; tb &= tb - 1) {
+        const int l = __ffsll((long long)tb) - 1;
+        float* tile = o.term.lidar + (size_t)(blockIdx.x * 64 + l) * lidar_words(c);
+        for (int e = s * 64 + lane; e < lidar_words(c); e += 64 * P) tile[e] = 1.0f;
+      }
+    }
+  }
   // ---- what this step's stacked observation may look at, BEFORE anything respawns (te_stacked.hpp SnapRows): every wave its slots' rows
   if (p.snap && valid) {
     const SnapRows sr{D, P};
@@ -745,11 +813,25 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
 #pragma unroll
   for (int u = 0; u < SPW; ++u)
     if (has[u]) { L(R.npos(0, sl[u])) = __float_as_uint(mx[u]); L(R.npos(1, sl[u])) = __float_as_uint(my[u]); L(R.npos(2, sl[u])) = __float_as_uint(mz[u]); }
+  if (LIDAR && o.term.lidar && term_b) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the terminal tiles has landed
   TE_WSTAMP(4, 0);
   TE_SLOT_BARRIER();
   TE_WSTAMP(5, 0);
 
   // ---- P4 --------------------------------------------------------------------------------------------------------------------------------
+  if (LIDAR) {
+    const uint32_t owners = L(R.accOwn());
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) {
+      if (has[u] && sl[u] >= 1) {
+        if (to_terminal && own[u] && o.term.lidar) patch(o.term.lidar, cj[u], rh[u], sl[u]);
+        // persistent observation: which cells of the MAIN buffer hold a feature now, in slot order
+        if (o.persist && o.obs.lidar && valid && own[u] && !to_terminal)
+          o.prev[env + (size_t)(__popc(owners & ((1u << (sl[u] & 31)) - 1u)) + 1) * p.Npad] = (uint16_t)cj[u];
+      }
+    }
+    if (s == 0 && o.persist && o.obs.lidar && valid) o.prev[env] = (uint16_t)(to_terminal ? 0 : __popc(owners));
+  }
   if (s == 0) {   // the observation of the state the step leaves (post-reset values for an auto-reset env)
     if (o.obs.inertial && valid) inertial_row_regs(c, o.obs.inertial + (size_t)env * TE_OBS_INERTIAL_WORDS, mx[0], my[0], mz[0], ag, mun, lf, step);
     if (valid && o.obs.last_action) reinterpret_cast<float4*>(o.obs.last_action)[env] = act;

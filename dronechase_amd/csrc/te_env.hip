@@ -897,8 +897,8 @@ struct te_env {
                                // chunk); 0 = engage_observe_kernel (LDS phases): other shapes, stage01 / stage02, TE_ENGAGE=lds
   int k1_help = 0;             // 1 = substeps_kernel<..., HELP>: a noise-helper wave next to every flight (small shards; TE_K1_HELP=0/1)
   int engage_slots = 0;        // 1 = engage_slots_kernel / engage_slots_stage02_kernel (te_engage_slots.hpp: one wave per (chunk, slot)) instead of engage_kernel;
-                               // 2 = engage_slots_stacked_kernel<slot_spw> with slot_waves waves (level5 family); TE_ENGAGE=regs turns them off
-  int slot_spw = 1, slot_waves = 0;
+                               // 2 = engage_slots_multi_kernel<slot_spw, own sphere> with slot_waves waves (level5 family, level5_2bt, large level4 shards); TE_ENGAGE=regs turns them off
+  int slot_spw = 1, slot_waves = 0; size_t slot_lds = 0;
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
   float* zero_actions = nullptr;     // te_step_students: the [N,4] action batch nobody reads (every pursuer is scripted)
   uint32_t* ally_scratch = nullptr;  // te_observe_wingman: owner planes between its two launches (te_create allocates them when a wingman is caller-driven)
@@ -1057,19 +1057,28 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     e->engage_slots = (long long)cfg->n_envs * D <= kSlotsMaxPairs ? 1 : 0;
     if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "slots")) e->engage_slots = 1; else if (!strcmp(v, "regs")) e->engage_slots = 0; }
   }
-  // the level5 family in the same form (engage_slots_stacked_kernel): wave w carries the slots w, w + W, ... (slot_spw of them)
-  if (regs_l4 && cfg->stacked_obs && D <= 32 && !cfg->drone_contact) {
-    // one slot per wave while the drones fit a workgroup; more slots per wave when the chip cannot hold every chunk's workgroup at once
-    // (256 CUs x 24 waves at <= 80 VGPRs): level5 x 65 536 envs ran in two rounds of nine-wave workgroups, 35 us; six waves of three slots: one round
+  // several slots per wave (engage_slots_multi_kernel): the level5 family (no own sphere; more drones than a workgroup has waves) and the level4
+  // family beyond 16 drones (level5_2bt: 2 + 30).  For the level5 family a large shard gets fewer, fatter waves: when the chip cannot hold every
+  // chunk's workgroup at once (256 CUs x 24 waves at <= 80 VGPRs) — level5 x 65 536 envs: nine-wave workgroups ran in two rounds, 35 us; six
+  // waves of three slots: 28 us
+  if (regs_l4 && D <= 32 && !cfg->drone_contact && (cfg->stacked_obs || D > kSlotWaves || e->engage_slots == 1)) {
     int spw = D <= kSlotWaves ? 1 : 2;
     const long long chunks = (cfg->n_envs + 63) / 64;
-    while (spw < 3 && chunks * ((D + spw - 1) / spw) > 256 * 24 && cfg->n_pursuers <= (D + spw) / (spw + 1)) spw += 1;
-    if (const char* v = getenv("TE_SLOT_SPW")) { const int k = atoi(v); if (k >= 1 && k <= 3 && (D + k - 1) / k <= kSlotWaves) spw = k; }
+    const int spw_max = cfg->stacked_obs ? 3 : 2;
+    // (with the own sphere, on shapes one slot per wave serves too, engage_slots_kernel stays ahead at every size — stage03 x 65 536: 81.8 vs
+    // 86.2 us per step, x 32 768: 51.0 vs 53.1, profiles/r04_q_ab_slots_per_wave.txt: most of its eleven waves retire at once — TE_SLOT_SPW=2 forces the other)
+    while (cfg->stacked_obs && spw < spw_max && chunks * ((D + spw - 1) / spw) > 256 * 24 && cfg->n_pursuers <= (D + spw) / (spw + 1)) spw += 1;
+    if (const char* v = getenv("TE_SLOT_SPW")) { const int k = atoi(v); if (k >= 1 && k <= spw_max && (D + k - 1) / k <= kSlotWaves) spw = k; }
     const int W = (D + spw - 1) / spw;
-    if (cfg->n_pursuers <= W && (size_t)stacked_slot_lds_rows(D, cfg->n_pursuers) * 256 <= 64 * 1024) {
-      e->engage_slots = 2; e->slot_spw = spw; e->slot_waves = W;
-      if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "regs")) e->engage_slots = 0; }
+    const size_t lds = (size_t)multi_slot_lds_rows(D, cfg->n_pursuers, !cfg->stacked_obs) * 256;
+    bool ok = cfg->n_pursuers <= W && lds <= 160 * 1024 && (cfg->stacked_obs || spw > 1);   // (one slot per wave with the own sphere: engage_slots_kernel)
+    if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "regs")) ok = false; }
+    if (ok && lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: level5_2bt's 32 drones with {cell, range} rows
+      const void* fn = cfg->stacked_obs ? (spw == 3 ? (const void*)engage_slots_multi_kernel<3, false> : spw == 2 ? (const void*)engage_slots_multi_kernel<2, false> : (const void*)engage_slots_multi_kernel<1, false>)
+                                        : (const void*)engage_slots_multi_kernel<2, true>;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); ok = false; }
     }
+    if (ok) { e->engage_slots = 2; e->slot_spw = spw; e->slot_waves = W; e->slot_lds = lds; }
   }
   if (e->family == FAM_STAGE02 && e->engage_regs == 3) {   // stage02 in the same form (engage_slots_stage02_kernel)
     e->engage_slots = (long long)cfg->n_envs * D <= kSlotsMaxPairs ? 1 : 0;
@@ -1392,9 +1401,10 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   StepOut o{reward, done, info, ObsOut{stack ? nullptr : obs_lidar, obs_inertial, obs_last_action},
             ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}, e->prev_cells, stack ? 0 : persist};
   const bool contact = p.cfg.drone_contact != 0;   // its own instantiations: the contact pass would cost every launch ~150 VGPRs
-  if (e->engage_slots == 2 && e->slot_spw == 1) TE_LAUNCH((engage_slots_stacked_kernel<1>), dim3(b2), dim3(64 * e->slot_waves), (size_t)stacked_slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
-  else if (e->engage_slots == 2 && e->slot_spw == 3) TE_LAUNCH((engage_slots_stacked_kernel<3>), dim3(b2), dim3(64 * e->slot_waves), (size_t)stacked_slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
-  else if (e->engage_slots == 2) TE_LAUNCH((engage_slots_stacked_kernel<2>), dim3(b2), dim3(64 * e->slot_waves), (size_t)stacked_slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
+  if (e->engage_slots == 2 && !stack) TE_LAUNCH((engage_slots_multi_kernel<2, true>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
+  else if (e->engage_slots == 2 && e->slot_spw == 1) TE_LAUNCH((engage_slots_multi_kernel<1, false>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
+  else if (e->engage_slots == 2 && e->slot_spw == 3) TE_LAUNCH((engage_slots_multi_kernel<3, false>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
+  else if (e->engage_slots == 2) TE_LAUNCH((engage_slots_multi_kernel<2, false>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
   else if (e->engage_slots && e->family == FAM_STAGE02) TE_LAUNCH((engage_slots_stage02_kernel<kSlotWaves>), dim3(b2), dim3(64 * p.D), (size_t)slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
   else if (e->engage_slots && !contact) TE_LAUNCH((engage_slots_kernel<kSlotWaves>), dim3(b2), dim3(64 * p.D), (size_t)slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
   else if (e->engage_regs == 1 && !contact) TE_LAUNCH((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, p, actions, o);

@@ -152,7 +152,7 @@ def _same_stacked_rollout(a, b, steps, seed=13, persistent=False):
     ("level5", 2048, {"n_invaders": 11, "n_rounds": 11, "max_step": 40}), ("level5", 2048, {"n_pursuers": 7, "n_invaders": 10, "n_rounds": 10, "max_step": 40}),
 ])
 def test_stacked_slot_waves_equal_the_one_wave_kernel(monkeypatch, task, n, over):
-    """engage_slots_stacked_kernel<1 / 2> (the level5 family: wave w carries the slots w, w + W, ...) against engage_kernel<6, 12>: every output of
+    """engage_slots_multi_kernel<1 / 2, false> (the level5 family: wave w carries the slots w, w + W, ...) against engage_kernel<6, 12>: every output of
     te_step_stacked, the terminal buffers and the state blob (snapshot ring included) along rollouts with shots, wave advances and auto-resets."""
     a, b = _pair(monkeypatch, task, n, **over)
     n_done = _same_stacked_rollout(a, b, 120)
@@ -172,4 +172,33 @@ def test_stacked_slot_waves_with_more_slots_per_wave(monkeypatch, task, spw, ove
     monkeypatch.delenv("TE_SLOT_SPW")
     n_done = _same_stacked_rollout(a, b, 100)
     assert n_done > 0 or "max_step" not in over
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("task,n,over", [
+    ("stage03", 4096, {}), ("stage03", 1000, {"seed": 5, "max_step": 25}), ("exp02", 2048, {}), ("evaluation", 2048, {}), ("stage03", 63, {"max_step": 12}),
+    ("stage03", 2048, {"lidar_channels": 2}), ("exp03", 2048, {"n_pursuers": 4, "n_invaders": 12, "n_rounds": 12, "max_step": 60}),
+])
+def test_two_slots_per_wave_with_the_own_sphere(monkeypatch, task, n, over):
+    """engage_slots_multi_kernel<2, true> (what a large level4 shard runs: six waves of two slots instead of eleven of one) against
+    engage_kernel, forced onto small shards: outputs, terminal buffers, state; then with the persistent observation."""
+    monkeypatch.setenv("TE_SLOT_SPW", "2")
+    a, b = _pair(monkeypatch, task, n, **over)
+    n_done = _same_rollout(a, b, 160)
+    assert n_done > 0 or "max_step" not in over
+    a.close(); b.close()
+    a, b = _pair(monkeypatch, task, n, **over)
+    monkeypatch.delenv("TE_SLOT_SPW")
+    _same_rollout(a, b, 60, persistent=True)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("n,over", [(4096, {}), (1000, {"seed": 2, "max_step": 40})])
+def test_level5_2bt_slot_waves_equal_the_one_wave_kernel(monkeypatch, n, over):
+    """level5_2bt (2 behaviour-tree wingmen + 30 invader slots, own sphere, evaluation rules): sixteen waves of two slots against engage_kernel<7, 30>."""
+    a, b = _pair(monkeypatch, "level5_2bt", n, **over)
+    _same_rollout(a, b, 200)
+    a.close(); b.close()
+    a, b = _pair(monkeypatch, "level5_2bt", n, **over)
+    _same_rollout(a, b, 60, persistent=True)
     a.close(); b.close()
