@@ -90,15 +90,35 @@ struct NavView {
 // the chunk's sparsely armed slots (Params::mixed_items), so `slot` is a per-lane value: the buffer addressing
 // (SlotLane: per-lane byte offset + scalar plane offset) is the same for both.
 // CES = cfg.control_every_substep (the reference's 240 Hz controller calls); false = PyFlyt-native 120 Hz
-template <int FAMILY, bool NOISE, bool MIXED, bool CES = true, bool HELP = false>
-TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, int env, bool valid, const float* nzbuf = nullptr, const volatile int* ready = nullptr) {
+// EAGER (the small-shard kernels: HELP): a lone flight's start is a chain of memory round trips — is the candidate live (`gate`: a scalar load
+// the caller has requested), is the lane armed, the state, and for an invader its FSM words and then the pursuers' reference positions — 3 to 5
+// of them before the first sub-step, of a 17 us flight.  Here a valid lane requests ALL of it at once, armed or not, before anything is looked
+// at (the invader's navigation then runs on registers: RegNav, at most kEagerP pursuers); a candidate with nothing to fly drops the requests.
+// Large shards keep the lazy form: their 10 000 dead candidates must not touch vector memory (te_env.hip, substeps_kernel).
+constexpr int kEagerP = 4;
+struct RegNav {   // kamikaze_update's view of the pursuers' reference positions (TE_X_REF), already in registers
+  float ref[3][kEagerP];
+  TE_DEV float gf(int w, int s) const {
+    float v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kEagerP; ++q) v = s == q ? ref[w - TE_D_OBS_POS][q] : v;
+    return v;
+  }
+};
+template <int FAMILY, bool NOISE, bool MIXED, bool CES = true, bool HELP = false, bool EAGER = false>
+TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, int env, bool valid, const float* nzbuf = nullptr, const volatile int* ready = nullptr, uint32_t gate = 1u) {
   const int D = p.D;
   const SlotLane P(p.dstate, p.estate, (uint32_t)D, (uint32_t)p.Npad, (uint32_t)slot, (uint32_t)env,
                    (uint32_t)(TE_DRONE_WORDS + TE_X_WORDS) * (uint32_t)D * (uint32_t)p.Npad, (uint32_t)TE_ENV_WORDS * (uint32_t)p.Npad);
-  const int armed = P.li(TE_D_ARMED);
-  const bool active = valid && armed != 0;
+  int armed = EAGER ? 0 : P.li(TE_D_ARMED);
+  const bool want = EAGER ? valid : (valid && armed != 0);   // the lanes that request their state now
   const te_config& c = p.cfg;
   const bool mode7 = (FAMILY == FAM_STAGE01) && slot == 2;
+  uint32_t nav_S = 0u; int nav_state = 0; V3 nav_me{0, 0, 0}; RegNav rnav;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int q = 0; q < kEagerP; ++q) rnav.ref[k][q] = 0.0f;
 
   // ---- every load of an armed lane is ISSUED before the background stores (in-order vmcnt: a load issued
   // after them could only be waited for together with them)
@@ -110,12 +130,19 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
   for (int k = 0; k < 29; ++k) raw[k] = 0.0f;
   V3 pf{0, 0, 0}, pt{0, 0, 0};
   uint32_t episode = 0, step_index = 0;
-  if (active) {
-    const bool scripted0 = FAMILY == FAM_LEVEL4 && all_scripted(c);  // Evaluation_Task / Level5DumbMultiObjectTask: pursuer 0 obeys the behaviour tree too
+  const bool scripted0 = FAMILY == FAM_LEVEL4 && all_scripted(c);  // Evaluation_Task / Level5DumbMultiObjectTask: pursuer 0 obeys the behaviour tree too
+  if (want) {
+    if (EAGER) armed = P.li(TE_D_ARMED);
     if (slot == 0 && !scripted0) act = reinterpret_cast<const float4*>(actions)[env];
     else if (FAMILY == FAM_LEVEL4) {
       if (slot < c.n_pursuers) {  // ally: command prepared by the previous engage/observe launch (or reset)
         cmd[0] = P.lf(TE_X_CMD + 0); cmd[1] = P.lf(TE_X_CMD + 1); cmd[3] = P.lf(TE_X_CMD + 2);
+      } else if (EAGER) {         // invader: everything KamikazeNavigator.update may look at (evaluated below, on registers)
+        nav_S = (uint32_t)P.lei(TE_E_SNAP_MASK); nav_state = P.li(TE_D_NAV_STATE);
+        nav_me = V3{P.lf(TE_D_OBS_POS), P.lf(TE_D_OBS_POS + 1), P.lf(TE_D_OBS_POS + 2)};
+#pragma unroll
+        for (int q = 0; q < kEagerP; ++q)
+          if (q < c.n_pursuers) { rnav.ref[0][q] = P.lf_slot(TE_X_REF + 0, q); rnav.ref[1][q] = P.lf_slot(TE_X_REF + 1, q); rnav.ref[2][q] = P.lf_slot(TE_X_REF + 2, q); }
       } else {                    // invader: KamikazeNavigator.update from the pursuers' last IMU positions
         const NavView nv{P, c.n_pursuers};
         const uint32_t S = (uint32_t)P.lei(TE_E_SNAP_MASK);
@@ -138,7 +165,17 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
     // stage01 counts step_calls BEFORE the sim loop (pyflyt_level2_environment_modified_v2.py:128)
     step_index = (uint32_t)P.lei(TE_E_STEP) + (FAMILY == FAM_STAGE01 ? 1u : 0u);
   }
+  if (EAGER) {
+    if (!gate) return;   // wave-uniform: a candidate with nothing to fly (its sibling wave takes the same exit)
+    if (HELP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the helper has cleared `ready`
+  }
+  const bool active = valid && armed != 0;
   if (!active) return;
+  if (EAGER && FAMILY == FAM_LEVEL4 && !(slot == 0 && !scripted0) && slot >= c.n_pursuers) {
+    float out[3];
+    nav_next = kamikaze_update(c, rnav, nav_S, nav_state, nav_me, out);
+    cmd[0] = out[0]; cmd[1] = out[1]; cmd[3] = out[2];
+  }
 
   // ---- set-point for this env.step
   float sp[4];
@@ -285,8 +322,8 @@ TE_DEV void fly(const Params& p, const float* __restrict__ actions, int slot, in
 // time (noise off: 21.3 -> 17.5 us at 8 192 envs) — so this wave computes it for all sub-steps, two per Philox call like the flight would, and
 // publishes row after row in LDS: nzbuf[sub-step][lane] = four normals, *ready = rows published.  Same functions, same operands, exact arithmetic:
 // the flight flies on the same bits (tests/test_gpu_noise_helper.py).
-template <int FAMILY>
-TE_DEV void noise_help(const Params& p, int slot, int env, bool valid, float* nzbuf, volatile int* ready) {
+template <int FAMILY, bool EAGER>
+TE_DEV void noise_help(const Params& p, int slot, int env, bool valid, float* nzbuf, volatile int* ready, uint32_t gate) {
   const te_config& c = p.cfg;
   const int lane = threadIdx.x & 63;
   const SlotLane P(p.dstate, p.estate, (uint32_t)p.D, (uint32_t)p.Npad, (uint32_t)slot, (uint32_t)env,
@@ -294,6 +331,11 @@ TE_DEV void noise_help(const Params& p, int slot, int env, bool valid, float* nz
   const int armed = P.li(TE_D_ARMED);
   const uint32_t episode = (uint32_t)P.lei(TE_E_EPISODE);
   const uint32_t step_index = (uint32_t)P.lei(TE_E_STEP) + (FAMILY == FAM_STAGE01 ? 1u : 0u);
+  if (EAGER) {   // (as the flight: requests first, then the candidate's flag; the lazy form has passed both in the kernel)
+    if (!gate) return;
+    if (lane == 0) *ready = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
   if (__ballot(valid && armed != 0) == 0ull) return;   // the flight has nothing armed either and retires without asking
   const int S = c.substeps;
   for (int s = 0; s < S; s += 2) {
@@ -376,12 +418,8 @@ __global__ __launch_bounds__(HELP ? 128 : TE_K1_BLOCK) TE_K1_ATTR void substeps_
     const int i = m * 64 + lane;
     const bool valid = i < count;
     const uint32_t item = valid ? (uint32_t)p.mixed_items[(size_t)chunk * kMixedCap + i] : 0u;
-    if (HELP) {
-      if (role == 1 && lane == 0) *ready = 0;
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (role == 1) { noise_help<FAMILY>(p, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid, k1_lds, ready); return; }
-    }
-    fly<FAMILY, NOISE, true, CES, HELP>(p, actions, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid, k1_lds, ready);
+    if (HELP && role == 1) { noise_help<FAMILY, true>(p, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid, k1_lds, ready, 1u); return; }
+    fly<FAMILY, NOISE, true, CES, HELP, HELP>(p, actions, (int)(item >> 8), chunk * 64 + (int)(item & 63u), valid, k1_lds, ready);
     TE_K1_END(3);
     return;
   }
@@ -393,12 +431,19 @@ __global__ __launch_bounds__(HELP ? 128 : TE_K1_BLOCK) TE_K1_ATTR void substeps_
   // to wait for a vector flag load (and issue a background store) behind the fill waves' stores: +15 us per launch.
   const uint32_t* __restrict__ sm32 = reinterpret_cast<const uint32_t*>(p.slot_mask);
   const uint32_t chunk_mask = __builtin_amdgcn_readfirstlane(sm32[2 * chunk + (slot >> 5)]);   // the 32-bit half that holds this slot's bit
-  if (!((chunk_mask >> (slot & 31)) & 1u)) { TE_K1_END(0); return; }
   const int env = chunk * 64 + lane;  // planes are padded to Npad: lanes beyond N still read in bounds
-  if (HELP) {
+  if (HELP && FAMILY == FAM_LEVEL4) {   // small shards: the flag is looked at behind the flight's (and the helper's) requests (fly<..., EAGER>)
+    const uint32_t gate = (chunk_mask >> (slot & 31)) & 1u;
+    if (role == 1) { noise_help<FAMILY, true>(p, slot, env, env < p.N, k1_lds, ready, gate); return; }
+    fly<FAMILY, NOISE, false, CES, true, true>(p, actions, slot, env, env < p.N, k1_lds, ready, gate);
+    TE_K1_END(2);
+    return;
+  }
+  if (!((chunk_mask >> (slot & 31)) & 1u)) { TE_K1_END(0); return; }
+  if (HELP) {   // (stage01 / stage02: two round trips in front of a flight, and the eager form measured 0.4 us slower there)
     if (role == 1 && lane == 0) *ready = 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (role == 1) { noise_help<FAMILY>(p, slot, env, env < p.N, k1_lds, ready); return; }
+    if (role == 1) { noise_help<FAMILY, false>(p, slot, env, env < p.N, k1_lds, ready, 1u); return; }
   }
   fly<FAMILY, NOISE, false, CES, HELP>(p, actions, slot, env, env < p.N, k1_lds, ready);
   TE_K1_END(2);
@@ -1092,8 +1137,9 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     return bail("te_create: cfg.drone_contact is built into engage_kernel: the level4 task family with P <= 6 and P + I <= 18");
   e->p.dense_min = kDenseMin;
   // noise-helper waves (substeps_kernel<..., HELP>): worth their issue slots only while SIMDs idle, i.e. on small shards
-  e->k1_help = (cfg->motor_noise && (long long)cfg->n_envs * D <= kHelpMaxPairs && cfg->substeps >= 2 && cfg->substeps <= 48) ? 1 : 0;
-  if (const char* v = getenv("TE_K1_HELP")) e->k1_help = (atoi(v) != 0 && cfg->motor_noise && cfg->substeps >= 2 && cfg->substeps <= 48) ? 1 : 0;
+  const bool help_ok = cfg->motor_noise && cfg->substeps >= 2 && cfg->substeps <= 48 && cfg->n_pursuers <= kEagerP;   // (the helped flights request eagerly: fly<..., EAGER>)
+  e->k1_help = (help_ok && (long long)cfg->n_envs * D <= kHelpMaxPairs) ? 1 : 0;
+  if (const char* v = getenv("TE_K1_HELP")) e->k1_help = (atoi(v) != 0 && help_ok) ? 1 : 0;
   if (const char* v = getenv("TE_DENSE_MIN")) { int n = atoi(v); if (n >= 1 && n <= 65) e->p.dense_min = n; }
   if (cfg->stacked_obs) e->n_fill_waves = 512;
   if (const char* v = getenv("TE_FILL_MODE")) e->fill_mode = atoi(v);
