@@ -177,6 +177,41 @@ struct EnvIO {
     for (int k = 0; k < 4; ++k) { stv(TE_D_THROTTLE + k, slot, 0u); stv(TE_D_SETPOINT + k, slot, 0u); }
     stv(TE_D_ARMED, slot, 1u); stv(TE_D_MUNITION, slot, (uint32_t)max_munition_of(c, slot)); stv(TE_D_LAST_FIRED, slot, (uint32_t)(-c.cooldown_steps));
   }
+  // spawn_slot_at for a WAVE-UNIFORM slot (the slot waves): the same words, every store with a scalar plane offset instead of a 64-bit pointer
+  // (40 stores x ~6 VALU instructions of address arithmetic were most of what a respawning wave added to its workgroup's chain)
+  TE_DEV bool spawn_uniform(const te_config& c, int env, int s, int round, uint32_t episode, bool reset, bool was_armed, V3& where) const {
+    const int Pn = c.n_pursuers;
+    const bool invader = s >= Pn;
+    const bool respawn = invader ? (s - Pn < invaders_in_round(c, round)) : reset;
+    if (respawn) {
+      const U4 r = invader ? env_rng(c, env, RNG_SPAWN_INVADER, (uint32_t)s, 0, episode, (uint32_t)round)
+                           : env_rng(c, env, RNG_SPAWN_PURSUER, (uint32_t)s, 0, episode, 0);
+      where = level4_position(c, invader ? c.born_radius : c.pursuer_spawn_radius, u01(r.x), u01(r.y));
+      const float w3[3] = {where.x, where.y, where.z};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        stf(TE_D_POS + k, s, w3[k]); stf(TE_D_FORMATION + k, s, w3[k]); stf(TE_D_OBS_POS + k, s, w3[k]);
+        st(TE_D_VEL + k, s, 0u); st(TE_D_OMEGA + k, s, 0u); st(TE_D_OBS_EULER + k, s, 0u); st(TE_D_OBS_VEL + k, s, 0u); st(TE_D_OBS_RATE + k, s, 0u);
+        st(TE_D_QUAT + k, s, 0u);
+      }
+      stf(TE_D_QUAT + 3, s, 1.0f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { st(TE_D_THROTTLE + k, s, 0u); st(TE_D_SETPOINT + k, s, 0u); }
+      st(TE_D_ARMED, s, 1u); st(TE_D_MUNITION, s, (uint32_t)max_munition_of(c, s)); st(TE_D_LAST_FIRED, s, (uint32_t)(-c.cooldown_steps));
+      if (!invader && driven_externally(c, s)) {   // Exp05_vFinal_Task.init_globals: last_action = zeros
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st(TE_D_ALLY_ACTION + k, s, 0u);
+      }
+    } else if (invader && was_armed) {   // disarm_all_invaders: the others are dead already, their words are zero
+      st(TE_D_ARMED, s, 0u);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { st(TE_D_VEL + k, s, 0u); st(TE_D_OMEGA + k, s, 0u); }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { st(TE_D_THROTTLE + k, s, 0u); st(TE_D_SETPOINT + k, s, 0u); }
+    }
+    if (invader || reset) st(TE_D_NAV_STATE, s, (uint32_t)TE_NAV_WAIT);
+    return respawn;
+  }
 };
 
 // cfg.drone_contact: armed drones as spheres of contact_radius, resolved once per env.step on the state the sub-step launch left, pairs

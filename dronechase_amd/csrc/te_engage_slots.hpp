@@ -328,7 +328,7 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
   if (task != 0u) {
     const bool reset = (task >> 8) != 0u;
     V3 w{0.0f, 0.0f, 0.0f};
-    const bool placed = spawn_slot_at(c, g, s, (int)(task & 0xFFu), episode, reset, ((A >> s) & 1u) != 0u, w);
+    const bool placed = io.spawn_uniform(c, env, s, (int)(task & 0xFFu), episode, reset, ((A >> s) & 1u) != 0u, w);
     if (placed) { mx = w.x; my = w.y; mz = w.z; }
     if (reset && is_p) { mun = max_munition_of(c, s); lf = -c.cooldown_steps; fx = mx; fy = my; fz = mz; }
   }
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
     for (int u = 0; u < SPW; ++u) {
       if (has[u]) {
         V3 w{0.0f, 0.0f, 0.0f};
-        const bool placed = spawn_slot_at(c, g, sl[u], (int)(task & 0xFFu), episode, reset, ((A >> (sl[u] & 31)) & 1u) != 0u, w);
+        const bool placed = io.spawn_uniform(c, env, sl[u], (int)(task & 0xFFu), episode, reset, ((A >> (sl[u] & 31)) & 1u) != 0u, w);
         if (placed) { mx[u] = w.x; my[u] = w.y; mz[u] = w.z; }
       }
     }
