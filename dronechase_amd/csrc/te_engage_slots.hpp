@@ -390,8 +390,8 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
     }
   }
   // ---- what the next sub-step launch has to fly for this chunk (post-spawn flags): a wave walks the slots up to its own and writes its
-  // items; the last pursuer wave walks them all and writes the chunk's masks
-  const int writer = P - 1;   // (always there; an invader wave may have retired)
+  // items; wave 0 walks them all and writes the chunk's masks
+  const int writer = 0;   // (always there; an invader wave may have retired.  The agent's wave has the shortest P4: rows only, no behaviour tree)
   if (s >= 1 || s == writer) {
     uint64_t dense = 0u, livem = 0u; int n = 0;
     uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
@@ -866,10 +866,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
       io.stf(TE_X_CMD + 0, s, out[0]); io.stf(TE_X_CMD + 1, s, out[1]); io.stf(TE_X_CMD + 2, s, out[2]);
     }
   }
-  // ---- the next sub-step launch's flight plan: a wave walks the slots up to its highest one and writes its own items; the last pursuer
-  // wave walks them all and writes the chunk's masks
+  // ---- the next sub-step launch's flight plan: a wave walks the slots up to its highest one and writes its own items; wave 0
+  // walks them all and writes the chunk's masks
   {
-    const int writer = P - 1;
+    const int writer = 0;   // (the agent's wave: no behaviour tree in its P4)
     int top = s;
 #pragma unroll
     for (int u = 1; u < SPW; ++u) if (has[u]) top = sl[u];
