@@ -133,6 +133,7 @@ struct ViewRows {
 };
 __host__ __device__ inline int view_lds_rows(int D) { return 10 * (D - 1) + 5 + 6 + 5; }
 constexpr int kViewThreads = 5 * 64;
+constexpr int kViewBatch = 8;   // ring features a wave of stack_view_kernel requests at once
 
 template <int DM>
 __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p, StackOut o) {
@@ -161,13 +162,21 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
       else own_ok = (int)load_fresh(own) == step;                 // te_observe_stacked: whatever the ring holds
       if (own_ok) {
         const int cnt = min((int)load_fresh(own + 1), r.F);   // (a ring that came in through te_set_state cannot overrun the list)
-        for (int k = 0; k < cnt; ++k) {
-          const te_w4 f = load_fresh4(own + TE_RING_HEADER_WORDS + 4 * k);
+        for (int k0 = 0; k0 < cnt; k0 += kViewBatch) {
+          te_w4 fb[kViewBatch];
+#pragma unroll
+          for (int i = 0; i < kViewBatch; ++i) fb[i] = load_fresh4(own + TE_RING_HEADER_WORDS + 4 * min(k0 + i, r.F - 1));
+#pragma unroll
+          for (int i = 0; i < kViewBatch; ++i) {
+          const int k = k0 + i;
+          if (k >= cnt) continue;
+          const te_w4 f = fb[i];
           const float thv = __uint_as_float(f.y), phv = __uint_as_float(f.z);
           const int ti = min(max((int)(thv / kPi * (float)TE_LIDAR_NTHETA), 0), TE_LIDAR_NTHETA - 1);
           const int pi = min(max((int)((phv + kPi) / (2.0f * kPi) * (float)TE_LIDAR_NPHI), 0), TE_LIDAR_NPHI - 1);
           row(r.list(0) + 2 * k, l) = (uint32_t)(ti * TE_LIDAR_NPHI + pi) | ((f.w & 0xFFu) << 16);
           row(r.list(0) + 2 * k + 1, l) = f.x;
+          }
         }
         own_n = (uint32_t)cnt;
       }
@@ -202,8 +211,16 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
         const int cnt = min((int)n0.y, r.F);
         const int base = r.list(1 + k);
         count = 0u;
-        for (int f = 0; f < cnt; ++f) {
-          const te_w4 ft = load_fresh4(nb + TE_RING_HEADER_WORDS + 4 * f);
+        // (the features are requested kViewBatch at a time, unconditionally — index clamped into the entry — before the first one is looked at:
+        // one request per iteration made a neighbour's list a chain of up to D - 1 memory round trips, most of this wave's time on a small shard)
+        for (int f0 = 0; f0 < cnt; f0 += kViewBatch) {
+          te_w4 fb[kViewBatch];
+#pragma unroll
+          for (int i = 0; i < kViewBatch; ++i) fb[i] = load_fresh4(nb + TE_RING_HEADER_WORDS + 4 * min(f0 + i, r.F - 1));
+#pragma unroll
+          for (int i = 0; i < kViewBatch; ++i) {
+          if (f0 + i >= cnt) continue;
+          const te_w4 ft = fb[i];
           const uint32_t meta = ft.w;
           if ((int)((meta >> 8) & 0xFFu) == ob) continue;  // synthetic echo of the observer itself (lidar_math.py:228-232)
           const float R = __uint_as_float(ft.x) * c.lidar_radius, thv = __uint_as_float(ft.y), phv = __uint_as_float(ft.z);
@@ -219,6 +236,7 @@ __global__ __launch_bounds__(kViewThreads) void stack_view_kernel(StackParams p,
           if (at >= 0) { const float cur = rowf(base + 2 * at + 1, l); put = cur < 1.0f ? rhat > cur : true; }
           else at = (int)count++;
           if (put) { row(base + 2 * at, l) = (uint32_t)cl | ((meta & 0xFFu) << 16); row(base + 2 * at + 1, l) = __float_as_uint(rhat); }
+          }
         }
       }
     }
