@@ -935,6 +935,7 @@ struct te_env {
   int family;
   size_t lds_bytes;
   size_t stack_lds_bytes = 0;  // stacked_kernel (level5)
+  int push_split = 0;          // 1 = ring_push_kernel<18, kPushSplit>: the binning of a (chunk, wingman) pair dealt over kPushSplit waves (small shards; TE_PUSH_SPLIT=0/1)
   int stack_regs = 0;          // 18 / 37: ring_push_kernel<DM> + stack_view_kernel<DM> (te_stackview.hpp); 0: stacked_kernel (more than 37 drones, TE_STACKED=lds)
   size_t view_lds_bytes = 0;
   size_t dbg_words = 0;       // diagnostic builds: length of p.dbg
@@ -1205,6 +1206,9 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     hipError_t le = hipFuncSetAttribute(reinterpret_cast<const void*>(&stacked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->stack_lds_bytes);
     e->stack_regs = D <= 18 ? 18 : (D <= 37 ? 37 : 0);
     if (const char* v = getenv("TE_STACKED")) { if (!strcmp(v, "lds")) e->stack_regs = 0; }
+    // small shards: fewer push waves than SIMDs even after dealing each pair's binning over kPushSplit waves
+    e->push_split = e->stack_regs == 18 && (long long)((cfg->n_envs + 63) / 64) * cfg->n_pursuers * kPushSplit <= 4096 ? 1 : 0;
+    if (const char* v = getenv("TE_PUSH_SPLIT")) e->push_split = e->stack_regs == 18 && atoi(v) != 0;
     e->view_lds_bytes = (size_t)view_lds_rows(D) * kEPB * sizeof(uint32_t);
     if (le == hipSuccess && e->stack_regs == 18) le = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_view_kernel<18>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->view_lds_bytes);
     if (le == hipSuccess && e->stack_regs == 37) le = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_view_kernel<37>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->view_lds_bytes);
@@ -1472,8 +1476,9 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
     if (e->stack_regs) {  // one wave per (chunk, wingman) pushes this step's ring entries, then one 5-wave workgroup per chunk and observer
       StackParams sp{p.cfg, p.snap, p.ring, p.N, p.Npad, p.D, p.entry_words, 1, 0, n_obs, persist, e->prev_cells};
       const unsigned push_waves = (unsigned)b2 * (unsigned)p.cfg.n_pursuers;
-      if (e->stack_regs == 18) TE_LAUNCH((ring_push_kernel<18>), dim3(push_waves), dim3(64), 0, sp);
-      else TE_LAUNCH((ring_push_kernel<37>), dim3(push_waves), dim3(64), 0, sp);
+      if (e->stack_regs == 18 && e->push_split) TE_LAUNCH((ring_push_kernel<18, kPushSplit>), dim3(push_waves), dim3(64 * kPushSplit), (size_t)4 * 18 * 256, sp);
+      else if (e->stack_regs == 18) TE_LAUNCH((ring_push_kernel<18, 1>), dim3(push_waves), dim3(64), 0, sp);
+      else TE_LAUNCH((ring_push_kernel<37, 1>), dim3(push_waves), dim3(64), 0, sp);
       for (int ob = 0; ob < n_obs; ++ob) {
         sp.push = ob == 0 ? 1 : 0; sp.observer = ob;   // the first view clears the ring of auto-reset envs when it is through
         if (prof_ext && ob == n_obs - 1) ev_b = pev[3];

@@ -25,13 +25,19 @@ TE_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::
 template <int N, class F>
 TE_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
-template <int DM>
-__global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
+// W > 1 (small shards: fewer (chunk, wingman) pairs than the chip has SIMDs, every push wave alone on its SIMD): the binning — 200 of the
+// wave's 250 instructions per drone — is dealt over the W waves of a workgroup (slot j to wave j mod W), handed over in LDS rows, and wave 0
+// alone runs closer-wins and writes the entry: a 12 us chain becomes ~5.  Same functions on the same operands: the entry is bit for bit the
+// one-wave kernel's.  Large shards keep W = 1 (the launch is VALU-bound there, the hand-over would only add to it).
+template <int DM, int W>
+__global__ __launch_bounds__(64 * W) void ring_push_kernel(StackParams p) {
+  extern __shared__ uint32_t push_sm[];   // W > 1: 4 * DM rows of 64 words
   const te_config& c = p.cfg;
   const int D = p.D, P = c.n_pursuers;
   const SnapRows sr{D, P};
   const int chunk = blockIdx.x / P, pp = blockIdx.x - chunk * P;
-  const int lane = threadIdx.x, env = chunk * kEPB + lane;
+  const int lane = threadIdx.x & 63, env = chunk * kEPB + lane;
+  const int w = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   // env < Npad always (the planes are padded to whole chunks), so every lane may read; the lanes beyond N contribute nothing
   auto snap = [&](int w) { return p.snap[(size_t)w * p.Npad + env]; };
   const bool live = env < p.N;
@@ -56,6 +62,7 @@ __global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
   static_for<DM>([&](auto J) {
     constexpr int j = decltype(J)::value;
     cell[j] = 0xFFFFFFFFu; rh[j] = 1.0f; th[j] = 0.0f; ph[j] = 0.0f;
+    if (W > 1 && (j % W) != w) return;   // another wave's slot
     if (j < hi && j != pp && ((A >> j) & 1u)) {
       const V3 pj{__uint_as_float(snap(sr.pos() + 0 * D + j)), __uint_as_float(snap(sr.pos() + 1 * D + j)), __uint_as_float(snap(sr.pos() + 2 * D + j))};
       const V3 local = rotate_by(qi, sub(pj, me));
@@ -64,6 +71,22 @@ __global__ __launch_bounds__(64) void ring_push_kernel(StackParams p) {
       cell[j] = (uint32_t)cl;
     }
   });
+  if (W > 1) {   // hand-over: every wave its slots' four words, then wave 0 collects
+    static_for<DM>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if ((j % W) != w || j >= hi) return;
+      push_sm[(0 * DM + j) * 64 + lane] = __float_as_uint(rh[j]); push_sm[(1 * DM + j) * 64 + lane] = __float_as_uint(th[j]);
+      push_sm[(2 * DM + j) * 64 + lane] = __float_as_uint(ph[j]); push_sm[(3 * DM + j) * 64 + lane] = cell[j];
+    });
+    __syncthreads();
+    if (w != 0) return;
+    static_for<DM>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if ((j % W) == 0 || j >= hi) return;
+      rh[j] = __uint_as_float(push_sm[(0 * DM + j) * 64 + lane]); th[j] = __uint_as_float(push_sm[(1 * DM + j) * 64 + lane]);
+      ph[j] = __uint_as_float(push_sm[(2 * DM + j) * 64 + lane]); cell[j] = push_sm[(3 * DM + j) * 64 + lane];
+    });
+  }
   // ---- closer wins per cell (lidar_math.py:262-311), as in stacked_kernel: j CLAIMS its cell if it is in view with r_hat < 1; the kept
   // feature of a cell is its closest claimant (ties: lowest slot); cells appear in the entry in the order of their first claimant.
   // Two drones in one of the sphere's 338 cells are rare (a pair collides in 4 % of the waves), and every pair was paying for the full
@@ -133,6 +156,7 @@ struct ViewRows {
 };
 __host__ __device__ inline int view_lds_rows(int D) { return 10 * (D - 1) + 5 + 6 + 5; }
 constexpr int kViewThreads = 5 * 64;
+constexpr int kPushSplit = 4;   // waves that share the binning of one (chunk, wingman) pair in ring_push_kernel<DM, W> on small shards
 constexpr int kViewBatch = 8;   // ring features a wave of stack_view_kernel requests at once
 
 template <int DM>

@@ -202,3 +202,28 @@ def test_level5_2bt_slot_waves_equal_the_one_wave_kernel(monkeypatch, n, over):
     a, b = _pair(monkeypatch, "level5_2bt", n, **over)
     _same_rollout(a, b, 60, persistent=True)
     a.close(); b.close()
+
+
+def _pair_var(monkeypatch, var, values, task, n, **over):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    from dronechase_amd import default_config
+    from dronechase_amd.batched_env import BatchedEnv
+    envs = []
+    for v in values:
+        monkeypatch.setenv(var, v)
+        envs.append(BatchedEnv(default_config(task, n_envs=n, **over), "cuda:0"))
+    monkeypatch.delenv(var)
+    return envs
+
+
+@pytest.mark.parametrize("task,n,over", [("level5", 2048, {"max_step": 30}), ("level5", 1000, {"seed": 7}), ("level5_c1", 2048, {"max_step": 30}),
+                                          ("level5", 63, {"max_step": 12})])
+def test_ring_push_dealt_over_four_waves_equals_the_one_wave_push(monkeypatch, task, n, over):
+    """ring_push_kernel<18, 4> (small shards: a (chunk, wingman) pair's binning dealt over four waves, LDS hand-over, wave 0 writes the entry)
+    against ring_push_kernel<18, 1>: stacked observation, masks, terminal buffers and the state blob with the snapshot ring."""
+    a, b = _pair_var(monkeypatch, "TE_PUSH_SPLIT", ("1", "0"), task, n, **over)
+    n_done = _same_stacked_rollout(a, b, 100)
+    assert n_done > 0 or "max_step" not in over
+    a.close(); b.close()
