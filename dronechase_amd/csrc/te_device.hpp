@@ -37,9 +37,9 @@ struct Derived {
 };
 constexpr int kMixedWaves = 2, kMixedCap = 64 * kMixedWaves;  // mixed waves per chunk; a slot that would overflow the list flies densely
 constexpr int kDenseMin = 40;                                // default of Params::dense_min: armed envs of a chunk from which a slot gets its own wave
+// (member order matters: the launch arguments are this 1 KB struct by value, and a wave's first requests need the POINTERS — with the two
+// configuration blocks in front of them the sub-step launch of an 8 192-env shard took 18.5 instead of 17.9 us, the engage launch 9.5 instead of 9.3)
 struct Params {
-  te_config cfg;
-  Derived kd;
   uint32_t* dstate;
   uint32_t* estate;
   int N, Npad, D;
@@ -63,6 +63,8 @@ struct Params {
   uint32_t* ring;
   int entry_words;
   unsigned long long* dbg;  // phase stamps of one block (diagnostic builds with -DTE_DEBUG_STAMPS only; else unused)
+  te_config cfg;
+  Derived kd;
 };
 #ifdef TE_DEBUG_STAMPS
 __device__ unsigned long long* g_te_dbg = nullptr;
