@@ -425,33 +425,39 @@ __global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const f
 // LDS rows of engage_slots_multi_kernel (256 B each): one record row per wingman; the {cell, range} pairs and the owner row behind the rest
 // (LIDAR only) — 30 KB for level5, four workgroups per CU
 struct MultiSlotRows {
-  int D, P;
-  TE_DEV int accS() const { return 0; }
-  TE_DEV int accZone() const { return 1; }
-  TE_DEV int accOrg() const { return 2; }
-  TE_DEV int pos(int k, int s) const { return 3 + k * D + s; }
-  TE_DEV int npos(int k, int s) const { return 3 + (3 + k) * D + s; }
-  TE_DEV int prec(int q) const { return 3 + 6 * D + q; }
-  TE_DEV int accOwn() const { return 3 + 6 * D + P; }
-  TE_DEV int cellr(int s) const { return 4 + 6 * D + P + 2 * s; }   // 8-byte {cell, range} per lane: two rows
+  int D, P, H;   // H = 32-bit halves of a slot mask: 1, or 2 beyond 32 drones (level5_fusion / level5_dumb)
+  TE_DEV int accS(int h = 0) const { return h; }
+  TE_DEV int accZone(int h = 0) const { return H + h; }
+  TE_DEV int accOrg(int h = 0) const { return 2 * H + h; }
+  TE_DEV int pos(int k, int s) const { return 3 * H + k * D + s; }
+  TE_DEV int npos(int k, int s) const { return 3 * H + (3 + k) * D + s; }
+  TE_DEV int prec(int q) const { return 3 * H + 6 * D + q; }
+  TE_DEV int accOwn() const { return 3 * H + 6 * D + P; }
+  TE_DEV int cellr(int s) const { return 3 * H + 1 + 6 * D + P + 2 * s; }   // 8-byte {cell, range} per lane: two rows
 };
-__host__ __device__ inline int multi_slot_lds_rows(int D, int P, bool lidar) { return 3 + 6 * D + P + (lidar ? 1 + 2 * D : 0); }
+__host__ __device__ inline int multi_slot_lds_rows(int D, int P, bool lidar) { return 3 * (D > 32 ? 2 : 1) + 6 * D + P + (lidar ? 1 + 2 * D : 0); }
 
-template <int SPW, bool LIDAR>
+template <int SPW, bool LIDAR, bool WIDE = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ? 4 : 6))) void engage_slots_multi_kernel(Params p, const float* __restrict__ actions, StepOut o) {
   TE_EXACT
   extern __shared__ uint32_t sm[];
   const te_config& c = p.cfg;
   const int D = p.D, P = c.n_pursuers;
   const int W = (int)(blockDim.x >> 6);
-  const MultiSlotRows R{D, P};
+  using M = typename std::conditional<WIDE, uint64_t, uint32_t>::type;   // one bit per slot (WIDE: up to 39 drones in 13 waves of 3)
+  constexpr M one = 1;
+  constexpr int kSh = WIDE ? 63 : 31;
+  static_assert(!(WIDE && LIDAR), "the own sphere's owner row is 32 bits");
+  const MultiSlotRows R{D, P, WIDE ? 2 : 1};
+  auto popcM = [](M m) { return WIDE ? __popcll((unsigned long long)m) : __popc((uint32_t)m); };
+  auto ffsM = [](M m) { return WIDE ? __ffsll((long long)m) - 1 : __ffs((int)(uint32_t)m) - 1; };
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave; its first slot
   const int env = blockIdx.x * 64 + lane;
   const bool valid = env < p.N;
   const GView g{p.dstate, p.estate, D, p.Npad, env, P};
   const EnvIO io(p, env);
-  const uint32_t pur_bits = (1u << P) - 1u, all_bits = D >= 32 ? ~0u : (1u << D) - 1u, inv_bits = all_bits & ~pur_bits;
+  const M pur_bits = (one << P) - one, all_bits = D >= (int)(8 * sizeof(M)) ? ~(M)0 : (one << D) - one, inv_bits = all_bits & ~pur_bits;
   const bool scripted = all_scripted(c);
   const bool is_p = s < P;
   int sl[SPW]; bool has[SPW];
@@ -464,12 +470,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
 
   // ---- P0 (see engage_slots_kernel) -------------------------------------------------------------------------------------------------------
   const uint32_t* __restrict__ lm32 = reinterpret_cast<const uint32_t*>(p.live_mask);
-  const uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane(lm32[2 * blockIdx.x]) & all_bits;   // D <= 32
+  const M live = (WIDE ? (M)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lm32[2 * blockIdx.x]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lm32[2 * blockIdx.x + 1]) << 32))
+                       : (M)(uint32_t)__builtin_amdgcn_readfirstlane(lm32[2 * blockIdx.x])) & all_bits;
   auto next_round_of = [&](int r) { return r + (r < c.n_rounds ? 1 : c.n_rounds); };   // advance_round (exp03_vFinal_task.py:155-175)
   auto may_be_spawned = [&](int slot, int r) { const int i = slot - P; return i < invaders_in_round(c, next_round_of(r)) || i < invaders_in_round(c, 1); };
   bool mine_live[SPW]; bool any_live = is_p;
 #pragma unroll
-  for (int u = 0; u < SPW; ++u) { mine_live[u] = has[u] && ((u == 0 && is_p) || ((live >> (sl[u] & 31)) & 1u)); any_live = any_live || mine_live[u]; }
+  for (int u = 0; u < SPW; ++u) { mine_live[u] = has[u] && ((u == 0 && is_p) || ((live >> (sl[u] & kSh)) & one) != 0); any_live = any_live || mine_live[u]; }
   if (!any_live) {   // none of this wave's slots is armed anywhere in the chunk, none can be armed by this step: the wave retires
     const int r = (int)io.le(TE_E_ROUND);
     bool maybe = false;
@@ -511,7 +518,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
   }
   uint32_t zero = 0u;
   asm volatile("" : "+s"(zero));
-  if (s == 0) { L(R.accS()) = 0u; L(R.accZone()) = 0u; L(R.accOrg()) = 0u; if (LIDAR) L(R.accOwn()) = 0u; }
+  if (s == 0) {
+#pragma unroll
+    for (int h = 0; h < (WIDE ? 2 : 1); ++h) { L(R.accS(h)) = 0u; L(R.accZone(h)) = 0u; L(R.accOrg(h)) = 0u; }
+    if (LIDAR) L(R.accOwn()) = 0u;
+  }
   TE_SLOT_BARRIER();   // barrier 0: the accumulator rows are zero
   int step = (int)w_step + 1;  // AGENT_STEP_BROADCAST (exp03_vFinal_environment.py:177-182)
   int max_step = (int)w_max_step, round = (int)w_round;
@@ -529,8 +540,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
     a_me[u] = (mine_live[u] && marmed_w[u] != zero && valid) ? 1u : 0u;
     if (has[u]) {
       const float n = fnorm(V3{mx[u], my[u], mz[u]});
-      const int sh = sl[u] & 31;
-      Lor(R.accS(), a_me[u] << sh); Lor(R.accZone(), (a_me[u] & (n > c.dome_radius ? 1u : 0u)) << sh); Lor(R.accOrg(), (a_me[u] & (n < c.origin_range ? 1u : 0u)) << sh);
+      const int sh = sl[u] & 31, hh = WIDE ? (sl[u] >> 5) & 1 : 0;   // the half that holds this slot's bit
+      Lor(R.accS(hh), a_me[u] << sh); Lor(R.accZone(hh), (a_me[u] & (n > c.dome_radius ? 1u : 0u)) << sh); Lor(R.accOrg(hh), (a_me[u] & (n < c.origin_range ? 1u : 0u)) << sh);
       L(R.pos(0, sl[u])) = __float_as_uint(mx[u]); L(R.pos(1, sl[u])) = __float_as_uint(my[u]); L(R.pos(2, sl[u])) = __float_as_uint(mz[u]);
     }
   }
@@ -551,16 +562,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
   TE_WSTAMP(2, 0);
   TE_SLOT_BARRIER();
   TE_WSTAMP(3, 0);
-  const uint32_t S = L(R.accS()), zone = L(R.accZone()), org = L(R.accOrg());
+  auto rdM = [&](int lo, int hi) { return WIDE ? (M)((uint64_t)L(lo) | ((uint64_t)L(hi) << 32)) : (M)L(lo); };
+  const M S = rdM(R.accS(0), R.accS(1)), zone = rdM(R.accZone(0), R.accZone(1)), org = rdM(R.accOrg(0), R.accOrg(1));
   const V3 apos{Lf(R.pos(0, 0)), Lf(R.pos(1, 0)), Lf(R.pos(2, 0))};
   // ---- pursuer wave: identify_closest_invader (offsets_handler.py:256-281), process_shoot_range_invaders /
   // process_explosion_range_invaders (exp03_vFinal_task.py:359-413) for ITS pursuer
   if (is_p) {
     int tgt = -1; float dmin = 0.0f;
-    for (uint32_t m = live & inv_bits; m; m &= m - 1u) {   // strict '<' in slot order, over the slots somebody of the chunk has armed
-      const int j = __ffs((int)m) - 1;
+    for (M m = live & inv_bits; m; m &= m - one) {   // strict '<' in slot order, over the slots somebody of the chunk has armed
+      const int j = ffsM(m);
       const float d = fdist(V3{mx[0], my[0], mz[0]}, V3{Lf(R.pos(0, j)), Lf(R.pos(1, j)), Lf(R.pos(2, j))});
-      const bool take = a_me[0] != 0u && ((S >> j) & 1u) != 0u && (tgt < 0 || d < dmin);
+      const bool take = a_me[0] != 0u && ((S >> j) & one) != 0 && (tgt < 0 || d < dmin);
       tgt = take ? j : tgt;
       dmin = take ? d : dmin;
     }
@@ -580,14 +592,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
   TE_SLOT_BARRIER();   // barrier 1b: the pursuers' records
 
   // ---- P3: the engagement, by every wave ----------------------------------------------------------------------------------------------------
-  uint32_t killed = 0u;
+  M killed = 0;
   int agent_shots = 0, ally_shots = 0, exploded = 0, pursuer_suicided = 0, agent_suicided = 0;
   for (int q = 0; q < P; ++q) {
     const uint32_t r = L(R.prec(q));
     const int t = (int)(r & 0xFFu) - 1;
-    if (r & SLOT_HIT) { killed |= 1u << t; if (q == 0) agent_shots += 1; else ally_shots += 1; }
+    if (r & SLOT_HIT) { killed |= one << t; if (q == 0) agent_shots += 1; else ally_shots += 1; }
     if (r & SLOT_EXPLODE) {
-      killed |= (1u << q) | (1u << t);
+      killed |= (one << q) | (one << t);
       if ((r & SLOT_SUICIDE) && q == 0) agent_suicided += 1;
       else if (r & SLOT_SUICIDE) pursuer_suicided += 1;
       else exploded += 1;
@@ -595,17 +607,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
   }
   // process_invaders_in_origin (:656-659); commented out in Evaluation_Task.on_step_middle (evaluation_task.py:397)
   if ((!c.evaluation || (c.evaluation & TE_EVAL_ORIGIN_RULE)) && valid) killed |= org & inv_bits;
-  const uint32_t A = S & ~killed;
+  const M A = S & ~killed;
 #pragma unroll
   for (int u = 0; u < SPW; ++u)
-    if (has[u] && ((killed >> (sl[u] & 31)) & 1u)) io.disarm(sl[u]);   // Quadcopter.disarm (quadcopter.py:461-478)
+    if (has[u] && ((killed >> (sl[u] & kSh)) & one)) io.disarm(sl[u]);   // Quadcopter.disarm (quadcopter.py:461-478)
   // increment_max_step (:150-153), compute_termination (:517-569)
   if (agent_shots + ally_shots > 0) max_step += c.step_increment;
-  const int armed_invaders = __popc(A & inv_bits), armed_pursuers = __popc(A & pur_bits);
+  const int armed_invaders = popcM(A & inv_bits), armed_pursuers = popcM(A & pur_bits);
   const bool all_rounds_over = armed_invaders == 0 && round >= c.n_rounds;
   bool term;
   if (c.evaluation) term = (c.max_step > 0 && step > max_step) || all_rounds_over || zone != 0u || armed_pursuers == 0;
-  else term = step > max_step || all_rounds_over || zone != 0u || armed_pursuers == 0 || (c.agent_death_terminates && !(A & 1u)) || apos.z < -5.99f;
+  else term = step > max_step || all_rounds_over || zone != 0u || armed_pursuers == 0 || (c.agent_death_terminates && !(A & one)) || apos.z < -5.99f;
   const bool to_terminal = valid && term && c.auto_reset;
   // ---- closer wins (lidar_math.py:262-311) as a fixed point: in every cell the armed drone of smallest (range, slot); a drone at range 1.0
   // never owns a cell.  Only slots some env of the chunk has armed can contest a cell.  Patches: flag = type / 5 (lidar_math.py:305), the
@@ -620,7 +632,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
     if (time_plane) dst[2 * TE_LIDAR_CELLS + cell] = 0.1f;
   };
   unsigned long long term_b = 0ull;
-  if (LIDAR) {
+  if constexpr (LIDAR) {
 #pragma unroll
     for (int u = 0; u < SPW; ++u) {
       if (has[u] && sl[u] >= 1) {
@@ -664,7 +676,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
       for (int k = 0; k < 3; ++k) p.snap[(size_t)(sr.euler() + k * P + s) * p.Npad + env] = eul[k];
     }
     if (s == 0) {
-      p.snap[(size_t)sr.armed() * p.Npad + env] = A; p.snap[(size_t)sr.armed_hi() * p.Npad + env] = 0u;
+      p.snap[(size_t)sr.armed() * p.Npad + env] = (uint32_t)A; p.snap[(size_t)sr.armed_hi() * p.Npad + env] = (uint32_t)((uint64_t)A >> 32);
       p.snap[(size_t)sr.step() * p.Npad + env] = (uint32_t)step;
       p.snap[(size_t)sr.episode() * p.Npad + env] = episode;
       p.snap[(size_t)sr.done() * p.Npad + env] = to_terminal ? 1u : 0u;
@@ -677,7 +689,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
     if (valid) {
       io.stef(TE_E_LAST_ACTION + 0, act.x); io.stef(TE_E_LAST_ACTION + 1, act.y); io.stef(TE_E_LAST_ACTION + 2, act.z); io.stef(TE_E_LAST_ACTION + 3, act.w);
       io.ste(TE_E_STEP, (uint32_t)step);
-      io.ste(TE_E_SNAP_MASK, S); io.ste(TE_E_SNAP_MASK_HI, 0u);
+      io.ste(TE_E_SNAP_MASK, (uint32_t)S); io.ste(TE_E_SNAP_MASK_HI, (uint32_t)((uint64_t)S >> 32));
     }
     agent_kills += agent_shots; allies_kills += ally_shots; deads += exploded;
     if (to_terminal) {
@@ -690,17 +702,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
       gun_state(c, mun, lf, step, max_munition_of(c, 0), gs);
       const float dist_origin = fnorm(apos);
       int ally = -1;  // identify_closest_ally (offsets_handler.py:167-190)
-      if ((S & 1u) && __popc(S & pur_bits) > 1) {
+      if ((S & one) && popcM(S & pur_bits) > 1) {
         float bd = 0.0f;
         for (int a = 1; a < P; ++a) {
-          if ((S >> a) & 1u) {
+          if ((S >> a) & one) {
             const float d = fdist(pos_of(a), apos);
             if (ally < 0 || d < bd) { ally = a; bd = d; }
           }
         }
       }
       const int chooser = ally < 0 ? 0 : ally;   // the reward's target: the closest invader of the agent's closest ally, or of the agent alone
-      const int target = ((S >> chooser) & 1u) ? (int)(sm[R.prec(chooser) * 64 + lane] & 0xFFu) - 1 : -1;
+      const int target = ((S >> chooser) & one) ? (int)(sm[R.prec(chooser) * 64 + lane] & 0xFFu) - 1 : -1;
       const V3 tp = target >= 0 ? pos_of(target) : V3{0.0f, 0.0f, 0.0f};
       cur_dist = fdist(apos, tp);
       const bool ready = gs[2] == 1.0f || gs[0] == 0.0f;
@@ -722,7 +734,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
         if (dist_origin > c.born_radius - 2.0f) penalty += fminf(dist_origin - (c.born_radius - 2.0f), 1000.0f);
         reward = clampf(score + bonus - penalty, -3000.0f, 3000.0f);
       } else if (c.reward_model == TE_REWARD_L5_C1) {  // Level5C1FusionTask.compute_reward (level5_c1_fusion_task.py:448-485)
-        const int t1 = (S & 1u) ? (int)(sm[R.prec(0) * 64 + lane] & 0xFFu) - 1 : -1;   // the agent's OWN closest invader (:458)
+        const int t1 = (S & one) ? (int)(sm[R.prec(0) * 64 + lane] & 0xFFu) - 1 : -1;   // the agent's OWN closest invader (:458)
         const float d1 = t1 >= 0 ? fdist(apos, pos_of(t1)) : dist_origin;
         const float first = last_dist == 0.0f ? d1 : last_dist;   // `last_distance` is set by the first reward of the env and never again (:467-468)
         float r1 = d1 < first ? c.approach_bonus_gain * fnorm(V3{ag[3], ag[4], ag[5]}) : 0.0f;
@@ -755,16 +767,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
 
   // ---- on_step_end (:321-333): next wave when this one is cleared and a pursuer is alive; SB3 auto-reset (every wave decides, wave 0 stores)
   uint32_t task = 0u;   // round | reset << 8: the slots of this env have to be respawned
-  uint32_t snap_mask = S;
+  M snap_mask = S;
   auto mask_after_spawn = [&](int rnd, bool reset) {
-    const uint32_t m = reset ? pur_bits : (A & pur_bits);
+    const M m = reset ? pur_bits : (A & pur_bits);
     const int n = invaders_in_round(c, rnd);
-    return (uint32_t)(m | ((uint32_t)((((uint64_t)1 << n) - 1u) << P) & all_bits));
+    return (M)(m | ((M)((((uint64_t)1 << n) - 1u) << P) & all_bits));
   };
   if (valid && !term && armed_invaders == 0 && armed_pursuers > 0) {
     round = round + (round < c.n_rounds ? 1 : c.n_rounds);  // advance_round (:155-175)
     snap_mask = mask_after_spawn(round, false);
-    if (s == 0) { io.ste(TE_E_ROUND, (uint32_t)round); io.ste(TE_E_SNAP_MASK, snap_mask); io.ste(TE_E_SNAP_MASK_HI, 0u); }
+    if (s == 0) { io.ste(TE_E_ROUND, (uint32_t)round); io.ste(TE_E_SNAP_MASK, (uint32_t)snap_mask); io.ste(TE_E_SNAP_MASK_HI, (uint32_t)((uint64_t)snap_mask >> 32)); }
     task = (uint32_t)round;
   }
   if (to_terminal) {  // Env.reset -> Task.on_reset (exp03_vFinal_environment.py:128-146): the env record by wave 0, every slot by its wave
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
       if (c.reward_model != TE_REWARD_L5_C1) io.stef(TE_E_LAST_DIST, c.dome_radius);
 #pragma unroll
       for (int k = 0; k < 4; ++k) io.ste(TE_E_LAST_ACTION + k, 0u);
-      io.ste(TE_E_SNAP_MASK, snap_mask); io.ste(TE_E_SNAP_MASK_HI, 0u);
+      io.ste(TE_E_SNAP_MASK, (uint32_t)snap_mask); io.ste(TE_E_SNAP_MASK_HI, (uint32_t)((uint64_t)snap_mask >> 32));
     }
     act = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
@@ -790,26 +802,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
     for (int u = 0; u < SPW; ++u) {
       if (has[u]) {
         V3 w{0.0f, 0.0f, 0.0f};
-        const bool placed = io.spawn_uniform(c, env, sl[u], (int)(task & 0xFFu), episode, reset, ((A >> (sl[u] & 31)) & 1u) != 0u, w);
+        const bool placed = io.spawn_uniform(c, env, sl[u], (int)(task & 0xFFu), episode, reset, ((A >> (sl[u] & kSh)) & one) != 0, w);
         if (placed) { mx[u] = w.x; my[u] = w.y; mz[u] = w.z; }
       }
     }
     if (reset && is_p) { mun = max_munition_of(c, s); lf = -c.cooldown_steps; fx = mx[0]; fy = my[0]; fz = mz[0]; }
   }
   if (s == 0 && __ballot(task != 0u) != 0ull) {   // the retired waves' share of Task.setup_round / on_reset: their invaders go back to WaitState
-    for (uint32_t m = inv_bits & ~live; m; m &= m - 1u) {
-      const int k2 = __ffs((int)m) - 1;
+    for (M m = inv_bits & ~live; m; m &= m - one) {
+      const int k2 = ffsM(m);
       const int wv = k2 % W;
       bool stayed = wv < P;   // did the wave that carries slot k2 stay?  (then it does this itself: spawn_slot_at)
       for (int u2 = 0; u2 < SPW && !stayed; ++u2) {
         const int s2 = wv + u2 * W;
-        if (s2 < D) stayed = ((live >> s2) & 1u) != 0u || __ballot(valid && may_be_spawned(s2, (int)w_round)) != 0ull;
+        if (s2 < D) stayed = ((live >> s2) & one) != 0 || __ballot(valid && may_be_spawned(s2, (int)w_round)) != 0ull;
       }
       if (stayed) continue;
       if (task != 0u) io.st(TE_D_NAV_STATE, k2, (uint32_t)TE_NAV_WAIT);
     }
   }
-  const uint32_t armed_post = task != 0u ? snap_mask : A;   // after the spawn: the pursuers as they are (all armed on reset) + the round's invaders
+  const M armed_post = task != 0u ? snap_mask : A;   // after the spawn: the pursuers as they are (all armed on reset) + the round's invaders
 #pragma unroll
   for (int u = 0; u < SPW; ++u)
     if (has[u]) { L(R.npos(0, sl[u])) = __float_as_uint(mx[u]); L(R.npos(1, sl[u])) = __float_as_uint(my[u]); L(R.npos(2, sl[u])) = __float_as_uint(mz[u]); }
@@ -819,7 +831,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
   TE_WSTAMP(5, 0);
 
   // ---- P4 --------------------------------------------------------------------------------------------------------------------------------
-  if (LIDAR) {
+  if constexpr (LIDAR) {
     const uint32_t owners = L(R.accOwn());
 #pragma unroll
     for (int u = 0; u < SPW; ++u) {
@@ -839,19 +851,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
   // ---- pursuer waves: TE_X_REF and the scripted wingman's command of the next step (loyalwingman_navigator.py:238-352)
   if (is_p && valid) {
     int first_skipped = -1;  // drive_loyalwingmen: get_armed_pursuers()[1:] — with the agent dead the first armed ally is skipped
-    if (!scripted && !(armed_post & 1u)) first_skipped = (armed_post & pur_bits & ~1u) ? __ffs((int)(armed_post & pur_bits & ~1u)) - 1 : -1;
+    if (!scripted && !(armed_post & one)) first_skipped = (armed_post & pur_bits & ~one) ? ffsM(armed_post & pur_bits & ~one) : -1;
     io.stf(TE_X_REF + 0, s, mx[0]); io.stf(TE_X_REF + 1, s, my[0]); io.stf(TE_X_REF + 2, s, mz[0]);
-    if ((s > 0 || scripted) && ((armed_post >> s) & 1u) && s != first_skipped) {
+    if ((s > 0 || scripted) && ((armed_post >> s) & one) && s != first_skipped) {
       float out[3] = {0.0f, 0.0f, 0.0f};
       const bool ext = driven_externally(c, s);
       if (!ext && c.ally_policy == TE_ALLY_BT) {
         const V3 me{mx[0], my[0], mz[0]};
         if (gun_available(c, mun, lf, step)) {
           int t = -1; float bd = 0.0f; V3 tp{0.0f, 0.0f, 0.0f};
-          if ((snap_mask >> s) & 1u) {
+          if ((snap_mask >> s) & one) {
             for (int j = P; j < D; ++j) {
-              if (__ballot((snap_mask >> j) & 1u) == 0ull) continue;   // nobody of the chunk has slot j armed: its row is not read
-              if ((snap_mask >> j) & 1u) {
+              if (__ballot(((snap_mask >> j) & one) != 0) == 0ull) continue;   // nobody of the chunk has slot j armed: its row is not read
+              if ((snap_mask >> j) & one) {
                 const V3 pj{Lf(R.npos(0, j)), Lf(R.npos(1, j)), Lf(R.npos(2, j))};
                 const float d = fdist(me, pj);
                 if (t < 0 || d < bd) { t = j; bd = d; tp = pj; }
@@ -877,7 +889,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SPW == 1 ?
     uint16_t* items = p.mixed_items + (size_t)blockIdx.x * kMixedCap;
     const int k_last = s == writer ? D - 1 : top;
     for (int k = 0; k <= k_last; ++k) {
-      const bool a = valid && ((armed_post >> k) & 1u) != 0u;
+      const bool a = valid && ((armed_post >> k) & one) != 0;
       const unsigned long long b = __ballot(a);
       const int cnt = __popcll(b);
       if (cnt == 0) continue;

@@ -1107,8 +1107,8 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
   // family beyond 16 drones (level5_2bt: 2 + 30).  For the level5 family a large shard gets fewer, fatter waves: when the chip cannot hold every
   // chunk's workgroup at once (256 CUs x 24 waves at <= 80 VGPRs) — level5 x 65 536 envs: nine-wave workgroups ran in two rounds, 35 us; six
   // waves of three slots: 28 us
-  if (regs_l4 && D <= 32 && !cfg->drone_contact && (cfg->stacked_obs || D > kSlotWaves || e->engage_slots == 1)) {
-    int spw = D <= kSlotWaves ? 1 : 2;
+  if (regs_l4 && (D <= 32 || (cfg->stacked_obs && D <= 3 * kSlotWaves)) && !cfg->drone_contact && (cfg->stacked_obs || D > kSlotWaves || e->engage_slots == 1)) {
+    int spw = D <= kSlotWaves ? 1 : D <= 2 * kSlotWaves ? 2 : 3;   // (beyond 32 drones — level5_fusion 36, level5_dumb 37 — the masks are 64 bits: <3, false, WIDE>)
     const long long chunks = (cfg->n_envs + 63) / 64;
     const int spw_max = cfg->stacked_obs ? 3 : 2;
     // (with the own sphere, on shapes one slot per wave serves too, engage_slots_kernel stays ahead at every size — stage03 x 65 536: 81.8 vs
@@ -1120,7 +1120,7 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     bool ok = cfg->n_pursuers <= W && lds <= 160 * 1024 && (cfg->stacked_obs || spw > 1);   // (one slot per wave with the own sphere: engage_slots_kernel)
     if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "regs")) ok = false; }
     if (ok && lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: level5_2bt's 32 drones with {cell, range} rows
-      const void* fn = cfg->stacked_obs ? (spw == 3 ? (const void*)engage_slots_multi_kernel<3, false> : spw == 2 ? (const void*)engage_slots_multi_kernel<2, false> : (const void*)engage_slots_multi_kernel<1, false>)
+      const void* fn = cfg->stacked_obs ? (D > 32 ? (const void*)engage_slots_multi_kernel<3, false, true> : spw == 3 ? (const void*)engage_slots_multi_kernel<3, false> : spw == 2 ? (const void*)engage_slots_multi_kernel<2, false> : (const void*)engage_slots_multi_kernel<1, false>)
                                         : (const void*)engage_slots_multi_kernel<2, true>;
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); ok = false; }
     }
@@ -1451,7 +1451,8 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   StepOut o{reward, done, info, ObsOut{stack ? nullptr : obs_lidar, obs_inertial, obs_last_action},
             ObsOut{stack ? nullptr : terminal_lidar, terminal_inertial, terminal_last_action}, e->prev_cells, stack ? 0 : persist};
   const bool contact = p.cfg.drone_contact != 0;   // its own instantiations: the contact pass would cost every launch ~150 VGPRs
-  if (e->engage_slots == 2 && !stack) TE_LAUNCH((engage_slots_multi_kernel<2, true>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
+  if (e->engage_slots == 2 && p.D > 32) TE_LAUNCH((engage_slots_multi_kernel<3, false, true>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
+  else if (e->engage_slots == 2 && !stack) TE_LAUNCH((engage_slots_multi_kernel<2, true>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
   else if (e->engage_slots == 2 && e->slot_spw == 1) TE_LAUNCH((engage_slots_multi_kernel<1, false>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
   else if (e->engage_slots == 2 && e->slot_spw == 3) TE_LAUNCH((engage_slots_multi_kernel<3, false>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
   else if (e->engage_slots == 2) TE_LAUNCH((engage_slots_multi_kernel<2, false>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);

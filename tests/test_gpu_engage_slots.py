@@ -227,3 +227,16 @@ def test_ring_push_dealt_over_four_waves_equals_the_one_wave_push(monkeypatch, t
     n_done = _same_stacked_rollout(a, b, 100)
     assert n_done > 0 or "max_step" not in over
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("task,n,over", [("level5_fusion", 4096, {}), ("level5_fusion", 1000, {"seed": 4, "max_step": 30}), ("level5_dumb", 4096, {}),
+                                          ("level5_dumb", 1000, {"seed": 6, "max_step": 30}), ("level5_dumb", 63, {"max_step": 12})])
+def test_wide_slot_waves_equal_the_one_wave_kernel(monkeypatch, task, n, over):
+    """engage_slots_multi_kernel<3, false, WIDE> (36 / 37 drones: thirteen waves of three slots, 64-bit slot masks) against engage_kernel<7, 30>."""
+    a, b = _pair(monkeypatch, task, n, **over)
+    n_done = _same_stacked_rollout(a, b, 120)
+    assert n_done > 0 or "max_step" not in over
+    a.close(); b.close()
+    a, b = _pair(monkeypatch, task, n, **over)
+    _same_stacked_rollout(a, b, 40, persistent=True)
+    a.close(); b.close()
