@@ -60,8 +60,10 @@ enum : uint32_t { SLOT_HIT = 1u << 8, SLOT_EXPLODE = 1u << 9, SLOT_SUICIDE = 1u 
 #define TE_WSTAMP(idx, wait) do {} while (0)
 #endif
 
-template <int DM>
-__global__ __launch_bounds__(DM * 64) void engage_slots_kernel(Params p, const float* __restrict__ actions, StepOut o) {
+// WPE: waves per SIMD the register budget is held to.  6 (75 VGPRs) by default; 8 (64 VGPRs, 24 B of scratch; TE_SLOT_WPE8=1) keeps one more
+// workgroup per CU in the heavy regimes of a large shard (steady-state engage 29.5 -> 26.2 us at 65 536 envs) and costs the light ones 1 us.
+template <int DM, int WPE = 6>
+__global__ __launch_bounds__(DM * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE > 6 ? WPE : 10))) void engage_slots_kernel(Params p, const float* __restrict__ actions, StepOut o) {
   TE_EXACT
   extern __shared__ uint32_t sm[];
   const te_config& c = p.cfg;

@@ -945,6 +945,7 @@ struct te_env {
   int engage_slots = 0;        // 1 = engage_slots_kernel / engage_slots_stage02_kernel (te_engage_slots.hpp: one wave per (chunk, slot)) instead of engage_kernel;
                                // 2 = engage_slots_multi_kernel<slot_spw, own sphere> with slot_waves waves (level5 family, level5_2bt, large level4 shards); TE_ENGAGE=regs turns them off
   int slot_spw = 1, slot_waves = 0; size_t slot_lds = 0;
+  int slot_wpe8 = 0;           // engage_slots_kernel<16, 8>: the 64-VGPR build, large shards (TE_SLOT_WPE8=0/1)
   int k2_threads = 256;        // engage/observe kernel: 512 when its LDS allows only two blocks per CU
   float* zero_actions = nullptr;     // te_step_students: the [N,4] action batch nobody reads (every pursuer is scripted)
   uint32_t* ally_scratch = nullptr;  // te_observe_wingman: owner planes between its two launches (te_create allocates them when a wingman is caller-driven)
@@ -1126,6 +1127,10 @@ __attribute__((visibility("default"))) int te_create(const te_config* cfg, int32
     }
     if (ok) { e->engage_slots = 2; e->slot_spw = spw; e->slot_waves = W; e->slot_lds = lds; }
   }
+  // (opt-in: at 65 536 envs the 64-VGPR build is ahead once the rollout is heavy — steady state 679 -> 700 M env-steps/s — and behind in the
+  // light window right after a reset, which is the one the driver's bench times: 910 -> 890 M; profiles/r04_w_ab_slot_waves_64_vgprs.txt)
+  e->slot_wpe8 = 0;
+  if (const char* v = getenv("TE_SLOT_WPE8")) e->slot_wpe8 = e->engage_slots == 1 && e->family == FAM_LEVEL4 && atoi(v) != 0;
   if (e->family == FAM_STAGE02 && e->engage_regs == 3) {   // stage02 in the same form (engage_slots_stage02_kernel)
     e->engage_slots = (long long)cfg->n_envs * D <= kSlotsMaxPairs ? 1 : 0;
     if (const char* v = getenv("TE_ENGAGE")) { if (!strcmp(v, "slots")) e->engage_slots = 1; else if (!strcmp(v, "regs")) e->engage_slots = 0; }
@@ -1457,6 +1462,7 @@ static int step_impl(te_env* e, const float* actions, float* obs_lidar, size_t l
   else if (e->engage_slots == 2 && e->slot_spw == 3) TE_LAUNCH((engage_slots_multi_kernel<3, false>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
   else if (e->engage_slots == 2) TE_LAUNCH((engage_slots_multi_kernel<2, false>), dim3(b2), dim3(64 * e->slot_waves), e->slot_lds, p, actions, o);
   else if (e->engage_slots && e->family == FAM_STAGE02) TE_LAUNCH((engage_slots_stage02_kernel<kSlotWaves>), dim3(b2), dim3(64 * p.D), (size_t)slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
+  else if (e->engage_slots && !contact && e->slot_wpe8) TE_LAUNCH((engage_slots_kernel<kSlotWaves, 8>), dim3(b2), dim3(64 * p.D), (size_t)slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
   else if (e->engage_slots && !contact) TE_LAUNCH((engage_slots_kernel<kSlotWaves>), dim3(b2), dim3(64 * p.D), (size_t)slot_lds_rows(p.D, p.cfg.n_pursuers) * 256, p, actions, o);
   else if (e->engage_regs == 1 && !contact) TE_LAUNCH((engage_kernel<2, 9>), dim3(b2), dim3(64), 0, p, actions, o);
   else if (e->engage_regs == 2 && !contact) TE_LAUNCH((engage_kernel<6, 12>), dim3(b2), dim3(64), 0, p, actions, o);
