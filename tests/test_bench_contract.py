@@ -53,5 +53,7 @@ def test_plain_multi_gpu_command_starts_its_own_ranks_before_touching_the_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--headline-only",
                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode != 0
-    assert out.stderr.count("bench.py needs an MI355X") >= 2 and "local_rank: 1" in out.stderr      # both ranks ran, under the elastic launcher
+    # the ranks ran under the elastic launcher (its failure report names a local rank); the launcher may end the second rank before it
+    # has printed its own message, so one message is enough
+    assert out.stderr.count("bench.py needs an MI355X") >= 1 and "local_rank:" in out.stderr and "torch.distributed.elastic" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
